@@ -1,0 +1,235 @@
+"""Generate golden vectors from the reference's own leaf modules (CPU, build container only).
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+The reference tree (/root/reference) is imported leaf-by-leaf through tests/golden/_ref_loader.py;
+it never travels to the GPU box -- only the small .npz fixtures written here do.  Inputs are
+regenerated in the tests from seeds (radardistill_amd.synthetic / numpy default_rng); weights are
+regenerated with tests/seeded.py::seeded_fill_, so fixtures hold expected OUTPUTS only (plus the
+few inputs that are cheaper to store than to re-derive).
+
+What each fixture pins is listed in DESIGN.md ("Oracle").  Third-party pieces that are absent here
+(torch_scatter, the DCN and iou3d CUDA extensions) are bridged by the oracle's restatement, so
+those specific arithmetic kernels are NOT pinned by these fixtures (they have their own
+known-answer tests).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from tests.golden import _ref_loader as L  # noqa: E402
+from tests.seeded import seeded_fill_  # noqa: E402
+from radardistill_amd.synthetic import make_batch, bench_geometry  # noqa: E402
+from oracle import bev as obev, head as ohead  # noqa: E402
+
+torch.set_grad_enabled(False)
+torch.set_num_threads(4)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()})
+    print("wrote", name, {k: tuple(np.asarray(v).shape) for k, v in arrs.items()})
+
+
+def g1_vfe():
+    mod = L.load("pcdet.models.backbones_3d.vfe.dynamic_pillar_vfe")
+    pc_range, voxel, grid = bench_geometry(128)
+    cfg = L.AttrDict(WITH_DISTANCE=False, USE_ABSLOTE_XYZ=True, USE_CLUSTER_XYZ=True, USE_NORM=True, NUM_FILTERS=[32])
+    batch = make_batch(batch_size=2, n_lidar=2000, n_radar=1000, n_boxes=4, grid=128, seed=1)
+    out = {}
+    for tag, cls, key, nfeat in (("radar", mod.Radar_DynamicPillarVFESimple2D, "radar_points", 6),
+                                 ("lidar", mod.DynamicPillarVFESimple2D, "points", 5)):
+        m = cls(model_cfg=cfg, num_point_features=nfeat, voxel_size=voxel, grid_size=grid, point_cloud_range=pc_range)
+        sd = m.state_dict(); seeded_fill_(sd, seed=11); m.load_state_dict(sd)
+        pts = torch.from_numpy(batch[key]).clone()
+        # a few points outside the range / on the border to exercise the mask
+        pts[:5, 1] = torch.tensor([pc_range[3] + 0.05, pc_range[0] - 0.01, pc_range[3], pc_range[0], 0.0])
+        for mode in ("eval", "train"):
+            m.train(mode == "train")
+            bd = m({key: pts.clone(), "batch_size": 2})
+            pre = "radar_" if tag == "radar" else ""
+            out[f"{tag}_{mode}_features"] = bd[pre + "pillar_features"]
+            out[f"{tag}_{mode}_coords"] = bd[pre + "pillar_coords"]
+        out[f"{tag}_running_mean_after"] = m.state_dict()["pfn_layers.0.norm.running_mean"]
+        out[f"{tag}_running_var_after"] = m.state_dict()["pfn_layers.0.norm.running_var"]
+    save("g1_vfe.npz", **out)
+
+
+BEV_CFG = dict(LAYER_NUMS=[5, 5], LAYER_STRIDES=[1, 2], NUM_FILTERS=[256, 256], UPSAMPLE_STRIDES=[1, 2],
+               NUM_UPSAMPLE_FILTERS=[128, 128])
+
+
+def _bev_inputs(seed, B=1, S=16):
+    g = np.random.default_rng(seed)
+    x4 = g.normal(0, 1, size=(B, 256, S, S)).astype(np.float32)
+    x4 *= (g.uniform(size=(B, 1, S, S)) < 0.4)            # sparse-looking map, like x_conv4.dense()
+    x5 = g.normal(0, 1, size=(B, 256, S // 2, S // 2)).astype(np.float32)
+    return torch.from_numpy(x4), torch.from_numpy(x5)
+
+
+def g2_dense_enc():
+    mod = L.load("pcdet.models.backbones_2d.base_bev_backbone")
+    m = mod.BaseBEVBackboneV2(L.AttrDict(BEV_CFG), input_channels=256)
+    sd = m.state_dict(); seeded_fill_(sd, seed=12); m.load_state_dict(sd)
+    x4, x5 = _bev_inputs(21)
+    out = {}
+    for mode in ("eval", "train"):
+        m.train(mode == "train")
+        d = m({"multi_scale_2d_features": {"x_conv4": x4, "x_conv5": x5}})
+        out[f"{mode}_2d_8x"] = d["spatial_features_2d_8x"]
+        out[f"{mode}_2d"] = d["spatial_features_2d"]
+    save("g2_dense_enc.npz", **out)
+
+
+def _install_dcn_bridge():
+    """The reference DCN op needs the compiled `DCN` extension (absent).  Bridge the module-level class
+    with the oracle restatement so the rest of ConvNeXtBlock / Radar_Distill runs as shipped."""
+    import math
+    import torch.nn as nn
+
+    class ModulatedDeformConv(nn.Module):
+        def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation=1, groups=1,
+                     deformable_groups=1, im2col_step=64, bias=True):
+            super().__init__()
+            self.stride, self.padding = stride, padding
+            self.weight = nn.Parameter(torch.zeros(out_channels, in_channels, kernel_size, kernel_size))
+            self.bias = nn.Parameter(torch.zeros(out_channels))
+            if not bias:
+                self.bias.requires_grad = False
+
+        def forward(self, x, offset, mask):
+            return obev.modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding)
+
+    L._stub("pcdet.ops.basicblock.modules.modulated_deform_conv", ModulatedDeformConv=ModulatedDeformConv)
+
+
+def g3_radar_distill():
+    _install_dcn_bridge()
+    mod = L.load("pcdet.models.backbones_2d.radar_distill_final")
+    cfg = L.AttrDict(dict(BEV_CFG, VOXEL_SIZE=[0.2, 0.2, 8.0], POINT_CLOUD_RANGE=[-12.8, -12.8, -5, 12.8, 12.8, 3]))
+    m = mod.Radar_Distill(cfg, input_channels=256)
+    sd = m.state_dict(); seeded_fill_(sd, seed=13); m.load_state_dict(sd)
+    x4, x5 = _bev_inputs(22, B=2)
+    out = {"n_params": np.array(sum(p.numel() for p in m.parameters()))}
+    keys = sorted(m.state_dict().keys())
+    out["state_keys"] = np.array(keys)
+    for mode in ("eval", "train"):
+        m.train(mode == "train")
+        d = m({"radar_multi_scale_2d_features": {"x_conv4": x4.clone(), "x_conv5": x5.clone()}})
+        ms = d["radar_multi_scale_2d_features"]
+        out[f"{mode}_8x_2"] = ms["radar_spatial_features_8x_2"]
+        out[f"{mode}_8x_1"] = ms["radar_spatial_features_8x_1"]
+        out[f"{mode}_2d_8x"] = d["radar_spatial_features_2d_8x"]
+        out[f"{mode}_2d"] = d["radar_spatial_features_2d"]
+    # losses on fresh random maps (AFD / PFD), incl. the NaN edge case
+    g = np.random.default_rng(23)
+    lid = torch.from_numpy(g.normal(0.2, 1, size=(2, 256, 16, 16)).astype(np.float32)) * \
+        torch.from_numpy((g.uniform(size=(2, 1, 16, 16)) < 0.5).astype(np.float32))
+    rad = torch.from_numpy(g.normal(0.0, 1, size=(2, 256, 16, 16)).astype(np.float32))
+    f, ml = m.low_loss(lid, rad)
+    out["afd_feature"], out["afd_mask"] = f, ml
+    # every lidar cell active -> no (radar active, lidar inactive) cell -> ratio x/0 = inf, 0*inf -> NaN
+    f2, ml2 = m.low_loss(lid.abs() + 1.0, rad)
+    out["afd_feature_nan"], out["afd_mask_nan"] = f2, ml2
+    hms = [torch.from_numpy(g.uniform(0, 1, size=(2, c, 16, 16)).astype(np.float32) ** 6) for c in (1, 2, 2, 1, 2, 2)]
+    logits = [{"hm": torch.from_numpy(g.normal(-2.0, 1.5, size=(2, c, 16, 16)).astype(np.float32))} for c in (1, 2, 2, 1, 2, 2)]
+    r1 = torch.from_numpy(g.normal(0, 1, size=(2, 256, 16, 16)).astype(np.float32))
+    r2 = torch.from_numpy(g.normal(0, 1, size=(2, 256, 16, 16)).astype(np.float32))
+    l1 = torch.from_numpy(g.normal(0, 1, size=(2, 256, 16, 16)).astype(np.float32))
+    l2 = torch.from_numpy(g.normal(0, 1, size=(2, 256, 16, 16)).astype(np.float32))
+    out["pfd"] = m.high_loss(r1, r2, l1, l2, hms, logits)
+    bd = {"multi_scale_2d_features": {"x_conv4": lid},
+          "radar_multi_scale_2d_features": {"radar_spatial_features_8x_2": rad, "radar_spatial_features_8x_1": r1},
+          "radar_spatial_features_2d": r1, "spatial_features_2d": l1,
+          "radar_spatial_features_2d_8x": r2, "spatial_features_2d_8x": l2,
+          "radar_pred_dicts": logits, "target_dicts": {"heatmaps": hms}}
+    total, tb = m.get_loss(bd)
+    out["get_loss_total"] = total
+    for k, v in tb.items():
+        out["tb_" + k] = np.float32(v)
+    save("g3_radar_distill.npz", **out)
+
+
+HEAD_CFG = dict(
+    DISTILL_PRED=True, CLASS_AGNOSTIC=False, IOU_REG="DIoU",
+    CLASS_NAMES_EACH_HEAD=[["car"], ["truck", "construction_vehicle"], ["bus", "trailer"], ["barrier"],
+                           ["motorcycle", "bicycle"], ["pedestrian", "traffic_cone"]],
+    SHARED_CONV_CHANNEL=64, USE_BIAS_BEFORE_NORM=True, NUM_HM_CONV=2,
+    SEPARATE_HEAD_CFG=dict(HEAD_ORDER=["center", "center_z", "dim", "rot", "vel", "iou"],
+                           HEAD_DICT={k: dict(out_channels=v, num_conv=2) for k, v in
+                                      dict(center=2, center_z=1, dim=3, rot=2, vel=2, iou=1).items()}),
+    RECTIFIER=0.5,
+    TARGET_ASSIGNER_CONFIG=dict(FEATURE_MAP_STRIDE=8, NUM_MAX_OBJS=500, GAUSSIAN_OVERLAP=0.1, MIN_RADIUS=2),
+    LOSS_CONFIG=dict(LOSS_WEIGHTS=dict(cls_weight=1.0, loc_weight=0.25,
+                                       code_weights=[1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2, 1.0, 1.0])),
+)
+CLASS_NAMES = ["car", "truck", "construction_vehicle", "bus", "trailer", "barrier", "motorcycle", "bicycle",
+               "pedestrian", "traffic_cone"]
+
+
+def g4_center_head():
+    # bridge the compiled iou3d extension with the oracle's C restatement (that arithmetic is then unpinned here)
+    L._stub("pcdet.ops.iou3d_nms.iou3d_nms_utils", boxes_aligned_iou3d_gpu=ohead.boxes_aligned_iou3d)
+    L.load("pcdet.models.model_utils.centernet_utils")
+    sys.modules["pcdet.utils.box_utils"].bbox3d_overlaps_diou = sys.modules[
+        "pcdet.models.model_utils.centernet_utils"].bbox3d_overlaps_diou
+    mod = L.load("pcdet.models.dense_heads.radar_center_head")
+    pc_range, voxel, grid = bench_geometry(128)
+    m = mod.Radar_CenterHead(L.AttrDict(HEAD_CFG), input_channels=256, num_class=10, class_names=CLASS_NAMES,
+                             grid_size=grid, point_cloud_range=pc_range, voxel_size=voxel,
+                             predict_boxes_when_training=False)
+    sd = m.state_dict(); seeded_fill_(sd, seed=14); m.load_state_dict(sd)
+    batch = make_batch(batch_size=2, n_lidar=16, n_radar=16, n_boxes=12, grid=128, seed=4)
+    gt = torch.from_numpy(batch["gt_boxes"]).clone()
+    gt[1, -3:, :] = 0            # padded rows (class 0 = 'bg'), as collate_batch produces
+    gt[0, 0, :2] = torch.tensor([pc_range[3] - 0.05, pc_range[1] + 0.05])   # near the border: clipped gaussian
+    g = np.random.default_rng(24)
+    feat = torch.from_numpy(g.normal(0, 1, size=(2, 256, 16, 16)).astype(np.float32))
+    m.train()
+    torch.set_grad_enabled(True)
+    d = m({"radar_spatial_features_2d": feat, "gt_boxes": gt.clone(), "batch_size": 2})
+    out = {"gt_boxes": gt}
+    for h, pd in enumerate(d["radar_pred_dicts"]):
+        for k, v in pd.items():
+            out[f"pred_{h}_{k}"] = v.detach()
+    td = d["target_dicts"]
+    for h in range(6):
+        out[f"hm_{h}"] = td["heatmaps"][h]; out[f"tb_{h}"] = td["target_boxes"][h]
+        out[f"ind_{h}"] = td["inds"][h]; out[f"mask_{h}"] = td["masks"][h]; out[f"gtbox_{h}"] = td["gt_box"][h]
+    loss, tb = m.get_loss()
+    torch.set_grad_enabled(False)
+    out["loss"] = loss.detach()
+    for k, v in tb.items():
+        out["tb_" + k] = np.float32(v)
+    save("g4_center_head.npz", **out)
+
+
+def g5_conv5():
+    L._stub("pcdet.utils.spconv_utils", replace_feature=None,
+            spconv=type("S", (), {"SparseModule": torch.nn.Module, "SparseSequential": torch.nn.Sequential}))
+    mod = L.load("pcdet.models.backbones_3d.spconv_backbone_2d")
+    from functools import partial
+    norm = partial(torch.nn.BatchNorm2d, eps=1e-3, momentum=0.01)
+    m = torch.nn.Sequential(mod.post_act_block_dense(256, 256, 3, norm_fn=norm, stride=2, padding=1),
+                            mod.BasicBlock(256, 256, norm_fn=norm), mod.BasicBlock(256, 256, norm_fn=norm))
+    sd = m.state_dict(); seeded_fill_(sd, seed=15); m.load_state_dict(sd)
+    x4, _ = _bev_inputs(25)
+    out = {}
+    for mode in ("eval", "train"):
+        m.train(mode == "train")
+        out[f"{mode}_x_conv5"] = m(x4)
+    save("g5_conv5.npz", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
+    fns = {"g1": g1_vfe, "g2": g2_dense_enc, "g3": g3_radar_distill, "g4": g4_center_head, "g5": g5_conv5}
+    for w in which:
+        fns[w]()

@@ -1,0 +1,192 @@
+"""CPU: the oracle restatement vs golden vectors produced by the reference's own leaf modules
+(tests/golden/make_golden.py).  These pin the oracle; the GPU tests then compare HIP vs oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bev, head, sparse, vfe
+from radardistill_amd.synthetic import bench_geometry, make_batch
+from tests.seeded import seeded_fill_
+
+torch.set_num_threads(4)
+
+
+def _close(a, b, rtol=1e-4, atol=1e-5):
+    a = a.detach().numpy() if torch.is_tensor(a) else np.asarray(a)
+    np.testing.assert_allclose(a, np.asarray(b), rtol=rtol, atol=atol)
+
+
+def _vfe_state(nfeat, seed=11):
+    cin = nfeat + 9
+    sd = {"pfn_layers.0.linear.weight": torch.zeros(32, cin), "pfn_layers.0.norm.weight": torch.zeros(32),
+          "pfn_layers.0.norm.bias": torch.zeros(32), "pfn_layers.0.norm.running_mean": torch.zeros(32),
+          "pfn_layers.0.norm.running_var": torch.ones(32),
+          "pfn_layers.0.norm.num_batches_tracked": torch.zeros((), dtype=torch.long)}
+    return seeded_fill_(sd, seed=seed)
+
+
+@pytest.mark.parametrize("tag,key,nfeat", [("radar", "radar_points", 6), ("lidar", "points", 5)])
+def test_g1_vfe(golden_dir, tag, key, nfeat):
+    g = np.load(f"{golden_dir}/g1_vfe.npz")
+    pc_range, voxel, grid = bench_geometry(128)
+    batch = make_batch(batch_size=2, n_lidar=2000, n_radar=1000, n_boxes=4, grid=128, seed=1)
+    pts = torch.from_numpy(batch[key]).clone()
+    pts[:5, 1] = torch.tensor([pc_range[3] + 0.05, pc_range[0] - 0.01, pc_range[3], pc_range[0], 0.0])
+    st = _vfe_state(nfeat)
+    for mode in ("eval", "train"):
+        out = vfe.dynamic_pillar_vfe(pts, st, "", pc_range, voxel, grid, training=(mode == "train"))
+        assert np.array_equal(out["pillar_coords"].numpy(), g[f"{tag}_{mode}_coords"])        # bit-exact ints
+        _close(out["pillar_features"], g[f"{tag}_{mode}_features"], rtol=1e-5, atol=1e-6)
+    _close(st["pfn_layers.0.norm.running_mean"], g[f"{tag}_running_mean_after"], 1e-5, 1e-7)
+    _close(st["pfn_layers.0.norm.running_var"], g[f"{tag}_running_var_after"], 1e-5, 1e-7)
+
+
+def _bev_inputs(seed, B=1, S=16):
+    g = np.random.default_rng(seed)
+    x4 = g.normal(0, 1, size=(B, 256, S, S)).astype(np.float32)
+    x4 *= (g.uniform(size=(B, 1, S, S)) < 0.4)
+    x5 = g.normal(0, 1, size=(B, 256, S // 2, S // 2)).astype(np.float32)
+    return torch.from_numpy(x4), torch.from_numpy(x5)
+
+
+def dense_enc_state(prefix=""):
+    sd = {}
+    for blk, cin0 in (("blocks.0.", 512), ("blocks.1.", 256)):
+        for k in range(6):
+            sd[f"{prefix}{blk}{1 + 3 * k}.weight"] = torch.zeros(256, cin0 if k == 0 else 256, 3, 3)
+            _bn_state(sd, f"{prefix}{blk}{2 + 3 * k}.", 256)
+    sd[prefix + "deblocks.0.0.weight"] = torch.zeros(256, 256, 2, 2)
+    _bn_state(sd, prefix + "deblocks.0.1.", 256)
+    return sd
+
+
+def _bn_state(sd, p, c):
+    sd[p + "weight"] = torch.zeros(c); sd[p + "bias"] = torch.zeros(c)
+    sd[p + "running_mean"] = torch.zeros(c); sd[p + "running_var"] = torch.ones(c)
+    sd[p + "num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+
+
+def test_g2_dense_enc(golden_dir):
+    g = np.load(f"{golden_dir}/g2_dense_enc.npz")
+    st = seeded_fill_(dense_enc_state(), seed=12)
+    x4, x5 = _bev_inputs(21)
+    for mode in ("eval", "train"):
+        up, feat = bev.dense_enc(x4, x5, st, "", training=(mode == "train"))
+        _close(up, g[f"{mode}_2d_8x"], 2e-4, 2e-5)
+        _close(feat, g[f"{mode}_2d"], 2e-4, 2e-5)
+
+
+def radar_distill_state(prefix=""):
+    sd = dense_enc_state(prefix)
+    for e in (1, 2, 3):
+        for n in (0, 1):
+            p = f"{prefix}encoder_{e}.{n}."
+            sd[p + "dwconv.weight"] = torch.zeros(256, 1, 7, 7); sd[p + "dwconv.bias"] = torch.zeros(256)
+            sd[p + "norm.weight"] = torch.zeros(256); sd[p + "norm.bias"] = torch.zeros(256)
+            sd[p + "pwconv1.weight"] = torch.zeros(1024, 256); sd[p + "pwconv1.bias"] = torch.zeros(1024)
+            sd[p + "grn.gamma"] = torch.zeros(1, 1, 1, 1024); sd[p + "grn.beta"] = torch.zeros(1, 1, 1, 1024)
+            sd[p + "pwconv2.weight"] = torch.zeros(256, 1024); sd[p + "pwconv2.bias"] = torch.zeros(256)
+            if n == 0:
+                sd[p + "conv_offset_mask1.weight"] = torch.zeros(27, 256, 3, 3)
+                sd[p + "conv_offset_mask1.bias"] = torch.zeros(27)
+                sd[p + "down_layer.weight"] = torch.zeros(256, 256, 3, 3); sd[p + "down_layer.bias"] = torch.zeros(256)
+        sd[f"{prefix}decoder_{e}.0.weight"] = torch.zeros(256, 256, 4, 4); sd[f"{prefix}decoder_{e}.0.bias"] = torch.zeros(256)
+        _bn_state(sd, f"{prefix}decoder_{e}.1.", 256)
+        sd[f"{prefix}agg_{e}.0.weight"] = torch.zeros(256, 512, 1, 1); sd[f"{prefix}agg_{e}.0.bias"] = torch.zeros(256)
+        _bn_state(sd, f"{prefix}agg_{e}.1.", 256)
+    return sd
+
+
+def test_g3_radar_distill_forward(golden_dir):
+    g = np.load(f"{golden_dir}/g3_radar_distill.npz")
+    st = radar_distill_state()
+    assert sorted(st.keys()) == sorted(g["state_keys"].tolist())      # state-dict naming contract (192 entries)
+    assert sum(v.numel() for k, v in st.items() if "running" not in k and "num_batches" not in k) == int(g["n_params"])
+    seeded_fill_(st, seed=13)
+    x4, x5 = _bev_inputs(22, B=2)
+    for mode in ("eval", "train"):
+        out = bev.radar_distill_forward(x4, x5, st, "", training=(mode == "train"))
+        _close(out["radar_spatial_features_8x_2"], g[f"{mode}_8x_2"], 5e-4, 5e-5)
+        _close(out["radar_spatial_features_8x_1"], g[f"{mode}_8x_1"], 5e-4, 5e-5)
+        _close(out["radar_spatial_features_2d_8x"], g[f"{mode}_2d_8x"], 5e-4, 5e-5)
+        _close(out["radar_spatial_features_2d"], g[f"{mode}_2d"], 5e-4, 5e-5)
+
+
+def test_g3_losses(golden_dir):
+    g = np.load(f"{golden_dir}/g3_radar_distill.npz")
+    r = np.random.default_rng(23)
+    lid = torch.from_numpy(r.normal(0.2, 1, size=(2, 256, 16, 16)).astype(np.float32)) * \
+        torch.from_numpy((r.uniform(size=(2, 1, 16, 16)) < 0.5).astype(np.float32))
+    rad = torch.from_numpy(r.normal(0.0, 1, size=(2, 256, 16, 16)).astype(np.float32))
+    f, m = bev.low_loss(lid, rad)
+    _close(f, g["afd_feature"], 1e-5); _close(m, g["afd_mask"], 1e-5)
+    f2, m2 = bev.low_loss(lid.abs() + 1.0, rad)
+    assert np.isnan(g["afd_feature_nan"]) and torch.isnan(f2)          # the reference's 0/0 edge case
+    _close(m2, g["afd_mask_nan"], 1e-5)
+    hms = [torch.from_numpy(r.uniform(0, 1, size=(2, c, 16, 16)).astype(np.float32) ** 6) for c in (1, 2, 2, 1, 2, 2)]
+    logits = [torch.from_numpy(r.normal(-2.0, 1.5, size=(2, c, 16, 16)).astype(np.float32)) for c in (1, 2, 2, 1, 2, 2)]
+    r1, r2, l1, l2 = [torch.from_numpy(r.normal(0, 1, size=(2, 256, 16, 16)).astype(np.float32)) for _ in range(4)]
+    _close(bev.high_loss(r1, r2, l1, l2, hms, logits), g["pfd"], 1e-5)
+    total, tb = bev.distill_loss(lid, {"radar_spatial_features_8x_2": rad, "radar_spatial_features_8x_1": r1,
+                                       "radar_spatial_features_2d": r1, "radar_spatial_features_2d_8x": r2},
+                                 l1, l2, hms, logits)
+    _close(total, g["get_loss_total"], 1e-5)
+    for k, v in tb.items():
+        _close(v, g["tb_" + k], 1e-5)
+
+
+def center_head_state(prefix=""):
+    sd = {prefix + "shared_conv.0.weight": torch.zeros(64, 256, 3, 3), prefix + "shared_conv.0.bias": torch.zeros(64)}
+    _bn_state(sd, prefix + "shared_conv.1.", 64)
+    for h, nc in enumerate((1, 2, 2, 1, 2, 2)):
+        for name, oc in list(head.HEAD_OUT.items()) + [("hm", nc)]:
+            p = f"{prefix}heads_list.{h}.{name}."
+            sd[p + "0.0.weight"] = torch.zeros(64, 64, 3, 3); sd[p + "0.0.bias"] = torch.zeros(64)
+            _bn_state(sd, p + "0.1.", 64)
+            sd[p + "1.weight"] = torch.zeros(oc, 64, 3, 3); sd[p + "1.bias"] = torch.zeros(oc)
+    return sd
+
+
+def test_g4_center_head(golden_dir):
+    g = np.load(f"{golden_dir}/g4_center_head.npz")
+    pc_range, voxel, grid = bench_geometry(128)
+    st = seeded_fill_(center_head_state(), seed=14)
+    r = np.random.default_rng(24)
+    feat = torch.from_numpy(r.normal(0, 1, size=(2, 256, 16, 16)).astype(np.float32))
+    gt = torch.from_numpy(g["gt_boxes"])
+    preds = head.center_head_forward(feat, st, "", 6, training=True)
+    for h, pd in enumerate(preds):
+        for k, v in pd.items():
+            _close(v, g[f"pred_{h}_{k}"], 2e-4, 2e-5)
+    from oracle.pillarnet import CLASS_NAMES, HEADS
+    td = head.assign_targets(gt, (16, 16), CLASS_NAMES, HEADS, pc_range, voxel)
+    for h in range(6):
+        _close(td["heatmaps"][h], g[f"hm_{h}"], 0, 0)                    # exact
+        _close(td["target_boxes"][h], g[f"tb_{h}"], 0, 0)
+        assert np.array_equal(td["inds"][h].numpy(), g[f"ind_{h}"])
+        assert np.array_equal(td["masks"][h].numpy(), g[f"mask_{h}"])
+        _close(td["gt_box"][h], g[f"gtbox_{h}"], 0, 0)
+    loss, tb = head.center_head_loss(preds, td, voxel, pc_range)
+    _close(loss, g["loss"], 1e-4)
+    for k, v in tb.items():
+        _close(v, g["tb_" + k], 2e-4, 1e-6)
+
+
+def test_g5_conv5(golden_dir):
+    g = np.load(f"{golden_dir}/g5_conv5.npz")
+    sd = {"0.0.weight": torch.zeros(256, 256, 3, 3)}
+    _bn_state(sd, "0.1.", 256)
+    for b in (1, 2):
+        for c in (1, 2):
+            sd[f"{b}.conv{c}.weight"] = torch.zeros(256, 256, 3, 3); sd[f"{b}.conv{c}.bias"] = torch.zeros(256)
+            _bn_state(sd, f"{b}.bn{c}.", 256)
+    seeded_fill_(sd, seed=15)
+    x4, _ = _bev_inputs(25)
+    import torch.nn.functional as F
+    for mode in ("eval", "train"):
+        tr = mode == "train"
+        y = F.conv2d(x4, sd["0.0.weight"], None, stride=2, padding=1)
+        y = F.relu(sparse.bn2d(y, sd, "0.1.", tr, 1e-3, 0.01))
+        y = sparse.dense_basic_block(y, sd, "1.", tr)
+        y = sparse.dense_basic_block(y, sd, "2.", tr)
+        _close(y, g[f"{mode}_x_conv5"], 2e-4, 2e-5)
