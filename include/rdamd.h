@@ -1,0 +1,170 @@
+/* rdamd.h -- C ABI of librdamd.so: the MI355X (gfx950) kernels of the RadarDistill training hot path.
+ *
+ * Drop-in boundary.  Plain pointers and sizes only; no torch / ATen types.
+ * All pointers are DEVICE pointers unless a parameter is named *_host.  All tensors are contiguous,
+ * feature maps are "rows x channels" (channels-last: a dense BEV map (B,C,H,W) is stored as
+ * rows (b,y,x) x C), float32 unless noted, indices int32.  `stream` is a hipStream_t passed as void*.
+ * Functions only enqueue work on `stream`; they never allocate or synchronise, except
+ * rd_index_* which documents its one device->host readback.  Scratch memory comes from the caller
+ * (`ws`, size from the matching *_ws_bytes function).
+ * Return value: 0 on success, negative RD_E* on error; rd_last_error() gives the message
+ * (the reference's ops raise c10::Error / exit(-1): modulated_deform_conv_cuda.cu:39-73, iou3d_nms.cpp:14-26;
+ * the Python host turns a non-zero code into RuntimeError).
+ *
+ * Each entry point cites the reference interface it replaces.
+ */
+#ifndef RDAMD_H
+#define RDAMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RD_OK 0
+#define RD_EINVAL (-1)   /* bad shape / argument */
+#define RD_EHIP (-2)     /* HIP runtime error at launch */
+#define RD_ENOSPC (-3)   /* workspace too small */
+
+const char *rd_last_error(void);
+int rd_abi_version(void);
+/* 1 if a gfx950 device is usable, 0 otherwise (never throws). */
+int rd_device_ok(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * A. Active-site index structures ("rulebooks").  Replaces spconv's hash-table indice-pair generation
+ *    (third-party spconv 2.x, call sites pcdet/models/backbones_3d/spconv_backbone_2d.py:9-28,264-269)
+ *    and torch.unique in pcdet/models/backbones_3d/vfe/dynamic_pillar_vfe.py:212.
+ *
+ *    A "rank grid" over a dense cell space of n_cells cells is a bitmap (1 bit / cell) plus an exclusive
+ *    popcount prefix per 32-bit word; the row of an active cell is prefix[word] + popc(bits below it), so rows
+ *    are sorted by cell number.  Layout of a rank-grid buffer (uint32): [n_words bitmap][n_words prefix][1 count]
+ *    [ceil(n_words/1024) scan scratch], n_words = ceil(n_cells / 32).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t rd_rankgrid_bytes(int64_t n_cells);
+
+/* Dynamic pillar voxelisation (dynamic_pillar_vfe.py:200-212,243-248).
+ * points (n_points, 1 + n_feat): col 0 = batch idx, cols 1..3 = x,y,z.  cell key = b*gx*gy + cx*gy + cy with
+ * cx = floor((x - x0)/vx), cy = floor((y - y0)/vy) (true fp32 division), points outside [0,g) dropped.
+ * Outputs: rankgrid over batch*gx*gy cells (zero-initialised inside), point_row[n_points] = pillar row or -1.
+ * After this call *count_dev (= rankgrid count word) holds the number of pillars P. */
+int rd_voxelize(const float *points, int n_points, int n_feat, int batch, int gx, int gy,
+                float x0, float y0, float vx, float vy, uint32_t *rankgrid, int32_t *point_row, void *stream);
+
+/* Pillar coordinates in row order: coords[P,3] = (b, y=cy, x=cx) int32 (dynamic_pillar_vfe.py:243-248).
+ * `xmajor` = 1 for the voxeliser's key order (b, cx, cy); 0 for cell = (b*H + y)*W + x grids. */
+int rd_rankgrid_coords(const uint32_t *rankgrid, int batch, int H, int W, int xmajor, int32_t *coords, int max_rows, void *stream);
+
+/* Generic: mark cells given by coords (n,3)=(b,y,x) in a (zeroed here) rank grid, then scan.  Rows of `coords`
+ * must be unique cells.  Used when a SparseConvTensor is built from caller-supplied, sorted indices. */
+int rd_rankgrid_from_coords(const int32_t *coords, int n, int batch, int H, int W, int xmajor, uint32_t *rankgrid, void *stream);
+
+/* SparseConv2d(k3,s2,p1) output set (spconv semantics): out cell (b,oy,ox) active iff an active input lies in its
+ * 3x3/stride-2 window.  in_coords (n_in,3).  Builds the output rank grid (Ho = (H-1)/2+1 ...). */
+int rd_rankgrid_downsample(const int32_t *in_coords, int n_in, int batch, int Ho, int Wo, uint32_t *out_rankgrid, void *stream);
+
+/* Neighbour tables.  nbr[n_out][9] int32: row of the input feeding tap t = ky*3+kx of output row j, or -1.
+ *   subm   : input == output set; tap reads (y+ky-1, x+kx-1).
+ *   strided: output (oy,ox) tap reads input (2*oy-1+ky, 2*ox-1+kx).
+ *   strided_T (for the data gradient): nbrT[n_in][9] = output row o that uses input i as its tap t, or -1. */
+int rd_nbr_subm(const int32_t *coords, int n, const uint32_t *rankgrid, int batch, int H, int W, int xmajor, int32_t *nbr, void *stream);
+int rd_nbr_strided(const int32_t *out_coords, int n_out, const uint32_t *in_rankgrid, int batch, int H, int W, int in_xmajor, int32_t *nbr, void *stream);
+int rd_nbr_strided_T(const int32_t *in_coords, int n_in, const uint32_t *out_rankgrid, int batch, int Ho, int Wo, int32_t *nbrT, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * B. Pillar feature encoder.  Replaces (Radar_)DynamicPillarVFESimple2D.forward + PFNLayerV2
+ *    (dynamic_pillar_vfe.py:14-46,195-313) incl. torch_scatter.scatter_mean / scatter_max.
+ * ---------------------------------------------------------------------------------------------- */
+/* Per-pillar xyz sums and counts: pillar_acc[P][4] = (sum x, sum y, sum z, count), zero-initialised inside. */
+int rd_vfe_pillar_mean(const float *points, int n_points, int n_feat, const int32_t *point_row, int n_pillars,
+                       float *pillar_acc, void *stream);
+/* Linear(Cin->32, no bias) of the 9+n_feat point features, and per-channel sum / sum of squares over the valid
+ * points (train-mode BatchNorm1d statistics).  stats[64] zero-initialised inside; stats[64] = n_valid as float at [64]. */
+int rd_vfe_linear_stats(const float *points, int n_points, int n_feat, const int32_t *point_row, const int32_t *coords,
+                        const float *pillar_acc, const float *weight /*[32][9+n_feat]*/, const float *geom /*[9]: vx,vy,vz,xoff,yoff,zoff,x0,y0,z0*/,
+                        float *stats /*[65]*/, void *stream);
+/* Linear -> affine (scale/shift = folded BatchNorm) -> ReLU -> per-pillar max.  out[P][32]; argmax[P][32]
+ * (point index of the maximum, smallest index on ties; may be NULL). */
+int rd_vfe_linear_bn_relu_max(const float *points, int n_points, int n_feat, const int32_t *point_row, const int32_t *coords,
+                              const float *pillar_acc, const float *weight, const float *geom,
+                              const float *scale, const float *shift, int n_pillars,
+                              float *out, int32_t *argmax, unsigned long long *ws_packed /*[P*32]*/, void *stream);
+/* Backward of the student VFE: grad_out[P][32] -> grad_weight[32][Cin], grad_gamma[32], grad_beta[32].
+ * mean/rstd = batch statistics saved by the forward; gamma = BN weight.  ws: n_points*32 floats + 128 floats. */
+int rd_vfe_backward(const float *points, int n_points, int n_feat, const int32_t *point_row, const int32_t *coords,
+                    const float *pillar_acc, const float *weight, const float *geom,
+                    const float *mean, const float *rstd, const float *gamma, const float *beta,
+                    const float *grad_out, const int32_t *argmax, int n_pillars, int n_valid,
+                    float *grad_weight, float *grad_gamma, float *grad_beta, float *ws, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * C. Convolution as gathered implicit GEMM on the matrix cores (fp32 MFMA).
+ *    One kernel family serves
+ *      - spconv SubMConv2d / SparseConv2d forward and data gradient (index mode TABLE),
+ *      - nn.Conv2d / nn.ConvTranspose2d on channels-last dense BEV maps (index modes DENSE / DENSE_T),
+ *      - nn.Linear / 1x1 conv (1 tap).
+ *    out[j][:] = act( (sum_t in[src(j,t)][:] @ W[:, t, :]^T + bias) * scale + shift + residual[j] )
+ *    Replaces: spconv gather-GEMM-scatter (spconv_backbone_2d.py:13-15,49-56), ATen/cuDNN conv2d
+ *    (base_bev_backbone.py:222-262, radar_distill_final.py:38-77, radar_center_head.py:40-45).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int mode;            /* 0 TABLE (nbr[n_out][taps]), 1 DENSE conv, 2 DENSE_T (transposed conv / data-grad of strided conv) */
+    const int32_t *nbr;  /* TABLE mode */
+    int B, Hin, Win, Hout, Wout;   /* dense modes: input / output map sizes */
+    int KH, KW, stride, pad;       /* dense modes */
+    int flip;            /* TABLE mode: 1 = read table column (taps-1-t) for weight tap t (SubM data gradient) */
+} rd_conv_index;
+
+/* weight_k: kernel layout [Cout][taps][Cin] (Cin contiguous).  bias/scale/shift/residual may be NULL.
+ * stats (may be NULL): [2*Cout] per-channel sum and sum of squares of the value BEFORE scale/shift/residual/act
+ * but after bias (accumulated with atomics; caller zeroes).  relu: 0/1.  Cin % 32 == 0 required. */
+int rd_conv_fwd(const float *in, int in_rows, int Cin, const float *weight_k, int taps, const float *bias,
+                float *out, int out_rows, int Cout, const rd_conv_index *idx,
+                const float *scale, const float *shift, const float *residual, int relu, float *stats, void *stream);
+
+/* Weight gradient: grad_wk[Cout][taps][Cin] += sum_j grad_out[j][:]^T (x) in[src(j,t)][:]  (atomic accumulation,
+ * caller zeroes).  Cout % 32 == 0 or Cout < 32 handled by masking; Cin % 32 == 0. */
+int rd_conv_wgrad(const float *in, int in_rows, int Cin, const float *grad_out, int out_rows, int Cout, int taps,
+                  const rd_conv_index *idx, float *grad_wk, void *stream);
+
+/* Weight layout transforms between parameter layouts and the kernel layout [Cout][taps][Cin].
+ *   kind 0: spconv [Cout][kh][kw][Cin]      -> same memory (copy), flip=1 reverses taps
+ *   kind 1: torch conv [Cout][Cin][kh][kw]  -> [Cout][taps][Cin]
+ *   kind 2: data-gradient operand: from kernel layout [Cout][taps][Cin] -> [Cin][taps][Cout], flip reverses taps
+ *   kind 3: torch ConvTranspose2d [Cin][Cout][kh][kw] -> kernel layout of the equivalent DENSE_T conv [Cout][taps][Cin]
+ *   kind 4: inverse of kind 1 (kernel layout grad -> torch conv layout); kind 5: inverse of kind 3 */
+int rd_weight_layout(const float *src, float *dst, int Cout, int Cin, int taps, int kind, int flip, void *stream);
+
+/* column sums: out[C] = sum_j x[j][:] (bias gradients); out zeroed inside. */
+int rd_colsum(const float *x, int64_t rows, int C, float *out, float *ws, int64_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * D. BatchNorm over rows (BatchNorm1d on sparse rows == BatchNorm2d on channels-last maps), fused with
+ *    residual add and ReLU.  Replaces nn.BatchNorm1d/2d + replace_feature round trips
+ *    (spconv_backbone_2d.py:61-77,80-112).
+ * ---------------------------------------------------------------------------------------------- */
+/* stats[2C] (sum, sumsq; e.g. from rd_conv_fwd or rd_bn_stats) -> mean/rstd (saved for backward), scale/shift,
+ * running stats update (momentum, unbiased var), all on device.  count = number of rows. */
+int rd_bn_stats(const float *x, int64_t rows, int C, float *stats /*[2C]*/, float *ws, int64_t ws_bytes, void *stream);
+int rd_bn_finalize(const float *stats, int64_t rows, int C, const float *gamma, const float *beta, float eps, float momentum,
+                   float *running_mean, float *running_var, float *mean, float *rstd, float *scale, float *shift, void *stream);
+/* y = x*scale + shift (+ residual) ; act: 0 none, 1 relu, 2 gelu(erf). */
+int rd_affine_act(const float *x, int64_t rows, int C, const float *scale, const float *shift, const float *residual,
+                  int act, float *y, void *stream);
+/* Backward of y = act(bn(x) + residual) in train mode.  Inputs: x (pre-BN), y (output, for the ReLU mask) or
+ * pre-activation recomputed for GELU, grad_y.  Outputs grad_x, grad_gamma, grad_beta, grad_residual (= masked grad_y,
+ * may alias NULL).  ws: see rd_bn_bwd_ws_bytes. */
+int64_t rd_bn_bwd_ws_bytes(int64_t rows, int C);
+int rd_bn_bwd(const float *x, const float *y, const float *grad_y, int64_t rows, int C, const float *gamma,
+              const float *mean, const float *rstd, const float *scale, const float *shift, int act, int has_residual,
+              float *grad_x, float *grad_res, float *grad_gamma, float *grad_beta, float *ws, int64_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * E. Sparse -> dense BEV (SparseConvTensor.dense(), spconv_backbone_2d.py:299) in channels-last, and back.
+ * ---------------------------------------------------------------------------------------------- */
+int rd_rows_to_dense(const float *feats, const int32_t *coords, int n, int C, int batch, int H, int W, float *dense, void *stream);
+int rd_dense_to_rows(const float *dense, const int32_t *coords, int n, int C, int batch, int H, int W, float *feats, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,217 @@
+"""torch.autograd glue around the HIP kernels (host side stays Python on PyTorch-ROCm, as BASELINE.json's
+north_star asks).  Each Function's forward and backward run hand-written kernels through the C ABI; torch only
+owns the tensors and the graph.
+"""
+import torch
+
+from . import kernels as K
+
+# bumped by the optimizer after every parameter update done through raw pointers (tensor._version does not see those)
+_WEIGHTS_EPOCH = [0]
+_LAYOUT_CACHE = {}
+
+
+def bump_weights_epoch():
+    _WEIGHTS_EPOCH[0] += 1
+
+
+def kernel_weight(param, Cout, Cin, taps, kind, flip=False):
+    """Parameter -> kernel layout [Cout][taps][Cin] (or its data-gradient transpose), cached per parameter version."""
+    key = (id(param), kind, flip)
+    ver = (param._version, _WEIGHTS_EPOCH[0], param.data_ptr())
+    hit = _LAYOUT_CACHE.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    src = param.detach()
+    if not src.is_contiguous():
+        src = src.contiguous()
+    if kind == 0 and not flip:
+        w = src.reshape(Cout, taps, Cin)          # spconv layout [Cout,kh,kw,Cin] and nn.Linear [Cout,Cin] are already kernel layout
+    else:
+        w = K.weight_layout(src, Cout, Cin, taps, kind, flip)
+    _LAYOUT_CACHE[key] = (ver, w)
+    return w
+
+
+class ConvSpec:
+    """Geometry of one convolution call: how output rows find their input rows, forward and backward.
+
+    fwd_ix / bwd_ix are rd_conv_index structs (kernels.conv_index_*); keep holds tensors referenced by raw pointer.
+    param_kind: 0 spconv / linear layout, 1 torch Conv2d layout, 3 torch ConvTranspose2d layout.
+    """
+
+    def __init__(self, taps, in_rows, out_rows, fwd_ix, bwd_ix, param_kind, keep=(), fwd_nbr=None, bwd_nbr=None):
+        self.taps, self.in_rows, self.out_rows = taps, in_rows, out_rows
+        self.fwd_ix, self.bwd_ix, self.param_kind = fwd_ix, bwd_ix, param_kind
+        self.keep = keep
+        self.fwd_nbr, self.bwd_nbr = fwd_nbr, bwd_nbr
+
+
+def dense_conv_spec(B, Hin, Win, KH, KW, stride, pad, transposed=False):
+    if not transposed:
+        Hout = (Hin + 2 * pad - KH) // stride + 1
+        Wout = (Win + 2 * pad - KW) // stride + 1
+        fwd = K.conv_index_dense(B, Hin, Win, Hout, Wout, KH, KW, stride, pad, transposed=False)
+        bwd = K.conv_index_dense(B, Hout, Wout, Hin, Win, KH, KW, stride, pad, transposed=True)
+        kind = 1
+    else:
+        Hout = (Hin - 1) * stride - 2 * pad + KH
+        Wout = (Win - 1) * stride - 2 * pad + KW
+        fwd = K.conv_index_dense(B, Hin, Win, Hout, Wout, KH, KW, stride, pad, transposed=True)
+        bwd = K.conv_index_dense(B, Hout, Wout, Hin, Win, KH, KW, stride, pad, transposed=False)
+        kind = 3
+    spec = ConvSpec(KH * KW, B * Hin * Win, B * Hout * Wout, fwd, bwd, kind)
+    spec.out_hw = (Hout, Wout)
+    return spec
+
+
+def linear_spec(rows):
+    fwd = K.conv_index_dense(1, rows, 1, rows, 1, 1, 1, 1, 0)
+    bwd = K.conv_index_dense(1, rows, 1, rows, 1, 1, 1, 1, 0)
+    return ConvSpec(1, rows, rows, fwd, bwd, 0)
+
+
+class _ConvFn(torch.autograd.Function):
+    """out = conv(x, W) + b with optional fused epilogue (eval-BN scale/shift, residual, ReLU) when no grad is needed,
+    or fused BatchNorm statistics (stats) in training."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, spec, Cout, stats):
+        Cin = x.shape[1]
+        wk = kernel_weight(weight, Cout, Cin, spec.taps, spec.param_kind if spec.param_kind != 0 else 0)
+        out = K.conv_fwd(x, wk, spec.taps, bias, spec.out_rows, Cout, spec.fwd_ix, stats=stats, nbr_keepalive=spec.fwd_nbr)
+        ctx.spec, ctx.Cout, ctx.Cin = spec, Cout, Cin
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight = ctx.saved_tensors
+        spec, Cout, Cin = ctx.spec, ctx.Cout, ctx.Cin
+        grad_out = grad_out.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wk = kernel_weight(weight, Cout, Cin, spec.taps, spec.param_kind if spec.param_kind != 0 else 0)
+            wd = K.weight_layout(wk, Cout, Cin, spec.taps, 2, False)          # [Cin][taps][Cout]
+            gx = K.conv_fwd(grad_out, wd, spec.taps, None, spec.in_rows, Cin, spec.bwd_ix, nbr_keepalive=spec.bwd_nbr)
+        if ctx.needs_input_grad[1]:
+            gwk = K.conv_wgrad(x, grad_out, spec.taps, spec.fwd_ix)             # kernel layout
+            if spec.param_kind == 0:
+                gw = gwk.reshape(weight.shape)
+            elif spec.param_kind == 1:
+                gw = K.weight_layout(gwk, Cout, Cin, spec.taps, 4, False, out_shape=tuple(weight.shape))
+            else:
+                gw = K.weight_layout(gwk, Cout, Cin, spec.taps, 5, False, out_shape=tuple(weight.shape))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = K.colsum(grad_out) if Cout % 4 == 0 else grad_out.sum(0)
+        return gx, gw, gb, None, None, None
+
+
+def conv(x, weight, bias, spec, Cout, stats=None):
+    return _ConvFn.apply(x, weight, bias, spec, Cout, stats)
+
+
+def conv_inference(x, weight, bias, spec, Cout, scale=None, shift=None, residual=None, relu=False):
+    """Frozen path (teacher): conv + folded eval-mode BatchNorm + residual + ReLU in ONE kernel, no graph."""
+    wk = kernel_weight(weight, Cout, x.shape[1], spec.taps, spec.param_kind if spec.param_kind != 0 else 0)
+    return K.conv_fwd(x, wk, spec.taps, bias, spec.out_rows, Cout, spec.fwd_ix, scale=scale, shift=shift, residual=residual,
+                      relu=relu, nbr_keepalive=spec.fwd_nbr)
+
+
+class _BNActFn(torch.autograd.Function):
+    """y = act(batchnorm_train(x) [+ residual]) over rows; batch statistics either precomputed by the producing conv
+    kernel's epilogue (`stats`) or computed here."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, act, stats):
+        rows, C = x.shape
+        if stats is None:
+            stats = K.bn_stats(x)
+        mean, rstd, scale, shift = K.bn_finalize(stats, rows, C, gamma, beta, eps, momentum, running_mean, running_var)
+        y = K.affine_act(x, scale, shift, residual, act)
+        ctx.act, ctx.has_res = act, residual is not None
+        ctx.save_for_backward(x, y, gamma, mean, rstd, scale, shift)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, gamma, mean, rstd, scale, shift = ctx.saved_tensors
+        gx, gres, gg, gb = K.bn_bwd(x, y, gy.contiguous(), gamma, mean, rstd, scale, shift, ctx.act, ctx.has_res)
+        return gx, gg, gb, gres, None, None, None, None, None, None
+
+
+def bn_act_train(x, bn, residual=None, act=1, stats=None):
+    """bn: nn.BatchNorm1d/2d module (train mode semantics: batch stats, running-stat update)."""
+    if x.shape[0] <= 1:
+        raise ValueError("Expected more than 1 value per channel when training")     # torch's own train-mode BN error
+    bn.num_batches_tracked += 1
+    return _BNActFn.apply(x, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, float(bn.eps), float(bn.momentum), act, stats)
+
+
+def bn_eval_scale_shift(bn):
+    """Folded eval-mode BatchNorm: y = x*scale + shift."""
+    rstd = torch.rsqrt(bn.running_var + bn.eps)
+    scale = bn.weight * rstd
+    shift = bn.bias - bn.running_mean * scale
+    return scale.detach().contiguous(), shift.detach().contiguous()
+
+
+class _BNEvalActFn(torch.autograd.Function):
+    """Eval-mode BN (+residual)(+act) that still backpropagates (student in eval(), rarely needed)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, residual, act):
+        y = K.affine_act(x, scale, shift, residual, act)
+        ctx.act = act
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(y, scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, scale = ctx.saved_tensors
+        if ctx.act == 2:
+            raise RuntimeError("backward through eval-mode BN+GELU is not implemented")
+        g = gy * (y > 0) if ctx.act == 1 else gy
+        return g * scale, None, None, (g if ctx.has_res else None), None
+
+
+def bn_act_eval(x, bn, residual=None, act=1):
+    scale, shift = bn_eval_scale_shift(bn)
+    if torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad)):
+        return _BNEvalActFn.apply(x, scale, shift, residual, act)
+    return K.affine_act(x, scale, shift, residual, act)
+
+
+class _RowsToDenseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, coords, batch, H, W):
+        ctx.save_for_backward(coords)
+        ctx.geom = (batch, H, W)
+        return K.rows_to_dense(feats, coords, batch, H, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        (coords,) = ctx.saved_tensors
+        b, H, W = ctx.geom
+        return K.dense_to_rows(g.contiguous(), coords, b, H, W), None, None, None, None
+
+
+def rows_to_dense(feats, coords, batch, H, W):
+    return _RowsToDenseFn.apply(feats, coords, batch, H, W)
+
+
+# ------------------------------------------------------------------------------------------ dense map helpers
+def nchw_to_rows(x):
+    """(B,C,H,W) tensor -> (rows (B*H*W, C) view/copy, B, H, W).  Channels-last memory is a free view."""
+    B, C, H, W = x.shape
+    xr = x.permute(0, 2, 3, 1)
+    if not xr.is_contiguous():
+        xr = xr.contiguous()
+    return xr.reshape(B * H * W, C), B, H, W
+
+
+def rows_to_nchw(rows, B, H, W):
+    """(B*H*W, C) rows -> logical (B,C,H,W) tensor in channels-last memory (no copy)."""
+    return rows.view(B, H, W, rows.shape[1]).permute(0, 3, 1, 2)

@@ -1,0 +1,452 @@
+// Convolution as gathered implicit GEMM on the gfx950 matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32).
+// See include/rdamd.h section C.  One kernel family for sparse (rulebook/neighbour-table) and dense channels-last
+// convolutions, transposed convolutions and linear layers:
+//
+//     out[j][n] = epilogue( sum_t sum_c in[src(j,t)][c] * W[n][t][c] )
+//
+// Block tile 128 (rows) x BN (out channels), K step 32 input channels of one tap; 4 waves (one per SIMD).
+// A rows are gathered straight from HBM/L2 by `src(j,t)` (a neighbour-table entry or dense geometry), 128-byte
+// segments per row, staged through registers into a padded LDS image (row stride 36 floats: ds_read_b128 of
+// 16 rows x 4 floats is bank-conflict free); weights W[n][t][c..c+31] are staged the same way.  Double-buffered LDS,
+// next tile's global loads are in flight while the current tile runs on the MFMA pipe.  Taps for which no row of the
+// tile has a source are skipped (sparse rulebooks are far from full at the shallow stages).
+// MFMA operand maps (guide section 3): A: lane l holds A[i = l&31][k = l>>5]; B: B[k = l>>5][j = l&31];
+// C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+#include "common.hpp"
+
+using namespace rd;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128;
+constexpr int KB = 32;
+constexpr int LDK = KB + 4;  // padded LDS row (floats)
+constexpr int MAX_TAPS = 16;
+
+struct ConvArgs {
+    const float *in;
+    int in_rows, Cin;
+    const float *w;
+    int taps;
+    const float *bias;
+    float *out;
+    int out_rows, Cout;
+    rd_conv_index ix;
+    const float *scale, *shift, *residual;
+    int relu;
+    float *stats;
+};
+
+__device__ __forceinline__ int src_row(const ConvArgs &a, int j, int t) {
+    if (j >= a.out_rows) return -1;
+    const rd_conv_index &ix = a.ix;
+    if (ix.mode == 0) {
+        int tt = ix.flip ? (a.taps - 1 - t) : t;
+        return ix.nbr[(int64_t)j * a.taps + tt];
+    }
+    int ox = j % ix.Wout;
+    int oy = (j / ix.Wout) % ix.Hout;
+    int b = j / (ix.Wout * ix.Hout);
+    int ky = t / ix.KW, kx = t % ix.KW;
+    int iy, ixx;
+    if (ix.mode == 1) {
+        iy = oy * ix.stride - ix.pad + ky;
+        ixx = ox * ix.stride - ix.pad + kx;
+    } else {  // transposed: oy = iy*stride - pad + ky
+        int ny = oy + ix.pad - ky, nx = ox + ix.pad - kx;
+        if (ny < 0 || nx < 0 || (ny % ix.stride) || (nx % ix.stride)) return -1;
+        iy = ny / ix.stride;
+        ixx = nx / ix.stride;
+    }
+    if (iy < 0 || iy >= ix.Hin || ixx < 0 || ixx >= ix.Win) return -1;
+    return (b * ix.Hin + iy) * ix.Win + ixx;
+}
+
+template <int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int MI = WM / 32, NI = WN / 32;
+    constexpr int BP = BN / 32;  // B float4 loads per thread
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDK];
+    __shared__ int s_tapmask;
+    constexpr int BUF = (BM + BN) * LDK;  // floats per buffer: [A tile 128 x 36][B tile BN x 36]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int ld_r = tid >> 3, ld_c = (tid & 7) * 4;
+
+    // ---- which taps have any source row in this tile
+    if (tid == 0) s_tapmask = 0;
+    __syncthreads();
+    {
+        int mask = 0;
+        for (int p = 0; p < 4; ++p) {
+            int j = m0 + ld_r + 32 * p;
+            if ((tid & 7) == 0)
+                for (int t = 0; t < a.taps; ++t)
+                    if (src_row(a, j, t) >= 0) mask |= 1 << t;
+        }
+        if (mask) atomicOr(&s_tapmask, mask);
+    }
+    __syncthreads();
+    const int tapmask = s_tapmask;
+    const int kchunks = a.Cin / KB;
+    const int n_active = __popc(tapmask);
+    const int steps = n_active * kchunks;
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[4], rb[BP];
+    int rows[4];
+    int cur_tap = -1, tap_iter_mask = tapmask;
+
+    auto load_tile = [&](int s) {
+        int kc = (s % kchunks) * KB;
+        if (s % kchunks == 0) {  // next active tap
+            cur_tap = __ffs(tap_iter_mask) - 1;
+            tap_iter_mask &= tap_iter_mask - 1;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) rows[p] = src_row(a, m0 + ld_r + 32 * p, cur_tap);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (rows[p] >= 0) v = *reinterpret_cast<const f32x4 *>(a.in + (int64_t)rows[p] * a.Cin + kc + ld_c);
+            ra[p] = v;
+        }
+#pragma unroll
+        for (int p = 0; p < BP; ++p) {
+            int n = n0 + ld_r + 32 * p;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (n < a.Cout) v = *reinterpret_cast<const f32x4 *>(a.w + ((int64_t)n * a.taps + cur_tap) * a.Cin + kc + ld_c);
+            rb[p] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(lds + buf * BUF + (ld_r + 32 * p) * LDK + ld_c) = ra[p];
+#pragma unroll
+        for (int p = 0; p < BP; ++p) *reinterpret_cast<f32x4 *>(lds + buf * BUF + BM * LDK + (ld_r + 32 * p) * LDK + ld_c) = rb[p];
+    };
+
+    if (steps > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+    const int fr = lane & 31, fh = lane >> 5;
+    for (int s = 0; s < steps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < steps) load_tile(s + 1);
+        const float *Ab = lds + buf * BUF + (wm * WM + fr) * LDK + 4 * fh;
+        const float *Bb = lds + buf * BUF + BM * LDK + (wn * WN + fr) * LDK + 4 * fh;
+#pragma unroll
+        for (int kk = 0; kk < KB / 8; ++kk) {
+            f32x4 af[MI], bf[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const f32x4 *>(Ab + i * 32 * LDK + kk * 8);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const f32x4 *>(Bb + j * 32 * LDK + kk * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q], bf[j][q], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < steps) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue
+    float *red = lds;  // [2][BN] column sums for BatchNorm statistics (LDS is free now: last loop iteration ended with a barrier)
+    if (a.stats) {
+        for (int i = tid; i < 2 * BN; i += 256) red[i] = 0.f;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int col = n0 + wn * WN + j * 32 + fr;
+        const bool col_ok = col < a.Cout;
+        const float bias = (a.bias && col_ok) ? a.bias[col] : 0.f;
+        const float sc = (a.scale && col_ok) ? a.scale[col] : 1.f;
+        const float sh = (a.shift && col_ok) ? a.shift[col] : 0.f;
+        float csum = 0.f, csq = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (row < a.out_rows && col_ok) {
+                    float v = acc[i][j][r] + bias;
+                    csum += v;
+                    csq += v * v;
+                    v = fmaf(v, sc, sh);
+                    if (a.residual) v += a.residual[(int64_t)row * a.Cout + col];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    a.out[(int64_t)row * a.Cout + col] = v;
+                }
+            }
+        }
+        if (a.stats && col_ok) {
+            atomicAdd(&red[wn * WN + j * 32 + fr], csum);
+            atomicAdd(&red[BN + wn * WN + j * 32 + fr], csq);
+        }
+    }
+    if (a.stats) {
+        __syncthreads();
+        for (int i = tid; i < BN; i += 256) {
+            int col = n0 + i;
+            if (col < a.Cout) {
+                atomicAdd(&a.stats[col], red[i]);
+                atomicAdd(&a.stats[a.Cout + col], red[BN + i]);
+            }
+        }
+    }
+}
+
+static int validate_index(const rd_conv_index *ix, int taps, int in_rows, int out_rows, const char *who) {
+    RD_REQUIRE(ix != nullptr, "%s: index spec is NULL", who);
+    RD_REQUIRE(taps >= 1 && taps <= MAX_TAPS, "%s: taps=%d outside 1..%d", who, taps, MAX_TAPS);
+    if (ix->mode == 0) {
+        RD_REQUIRE(ix->nbr != nullptr || out_rows == 0, "%s: TABLE mode needs nbr", who);
+    } else {
+        RD_REQUIRE(ix->mode == 1 || ix->mode == 2, "%s: bad index mode %d", who, ix->mode);
+        RD_REQUIRE(ix->KH * ix->KW == taps, "%s: KH*KW=%d != taps=%d", who, ix->KH * ix->KW, taps);
+        RD_REQUIRE(ix->stride >= 1 && ix->pad >= 0, "%s: bad stride/pad", who);
+        RD_REQUIRE((int64_t)ix->B * ix->Hin * ix->Win == in_rows, "%s: in_rows=%d != B*Hin*Win=%lld", who, in_rows,
+                   (long long)ix->B * ix->Hin * ix->Win);
+        RD_REQUIRE((int64_t)ix->B * ix->Hout * ix->Wout == out_rows, "%s: out_rows=%d != B*Hout*Wout=%lld", who, out_rows,
+                   (long long)ix->B * ix->Hout * ix->Wout);
+    }
+    return RD_OK;
+}
+
+extern "C" int rd_conv_fwd(const float *in, int in_rows, int Cin, const float *weight_k, int taps, const float *bias, float *out,
+                           int out_rows, int Cout, const rd_conv_index *idx, const float *scale, const float *shift,
+                           const float *residual, int relu, float *stats, void *stream) {
+    RD_REQUIRE(Cin > 0 && Cin % KB == 0, "rd_conv_fwd: Cin=%d must be a multiple of %d", Cin, KB);
+    RD_REQUIRE(Cout > 0 && in_rows >= 0 && out_rows >= 0, "rd_conv_fwd: bad sizes");
+    int rc = validate_index(idx, taps, in_rows, out_rows, "rd_conv_fwd");
+    if (rc) return rc;
+    if (out_rows == 0) return RD_OK;
+    ConvArgs a{in, in_rows, Cin, weight_k, taps, bias, out, out_rows, Cout, *idx, scale, shift, residual, relu, stats};
+    hipStream_t st = S(stream);
+    dim3 block(256);
+    if (Cout > 64) {
+        dim3 grid((unsigned)cdiv(out_rows, BM), (unsigned)cdiv(Cout, 128));
+        k_conv_igemm<128, 2, 2><<<grid, block, 0, st>>>(a);
+    } else if (Cout > 32) {
+        dim3 grid((unsigned)cdiv(out_rows, BM), 1);
+        k_conv_igemm<64, 2, 2><<<grid, block, 0, st>>>(a);
+    } else {
+        dim3 grid((unsigned)cdiv(out_rows, BM), 1);
+        k_conv_igemm<32, 4, 1><<<grid, block, 0, st>>>(a);
+    }
+    return check_launch("rd_conv_fwd");
+}
+
+// ---------------------------------------------------------------------------------------------- weight gradient
+// grad_w[n][t][c] += sum_j grad_out[j][n] * in[src(j,t)][c].  GEMM with M = Cout tile (128), N = Cin tile (BNW), K = rows.
+// Both operands are k-major in memory (rows x channels), so LDS tiles are stored [k][m] and read with ds_read_b32
+// (consecutive lanes -> consecutive channels: conflict free).  Split over row chunks; fp32 atomics combine the chunks.
+constexpr int WG_KB = 32;   // rows per K step
+constexpr int WG_BM = 128;  // Cout tile
+constexpr int WG_BN = 64;   // Cin tile
+
+struct WgradArgs {
+    const float *in;
+    int in_rows, Cin;
+    const float *go;
+    int out_rows, Cout, taps;
+    rd_conv_index ix;
+    float *gw;
+    int rows_per_block;
+};
+
+__device__ __forceinline__ int src_row_w(const WgradArgs &a, int j, int t) {
+    ConvArgs c;
+    c.out_rows = a.out_rows;
+    c.taps = a.taps;
+    c.ix = a.ix;
+    return src_row(c, j, t);
+}
+
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad(const WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float G_l[2][WG_KB][WG_BM + 4];  // grad_out tile [k][cout]
+    __shared__ __attribute__((aligned(16))) float X_l[2][WG_KB][WG_BN + 4];  // gathered input tile [k][cin]
+    __shared__ int s_any[2];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;  // 2x2 waves: wave tile 64 (cout) x 32 (cin)
+    const int tile = blockIdx.y;            // (tap, mt, nt)
+    const int n_nt = (a.Cin + WG_BN - 1) / WG_BN;
+    const int n_mt = (a.Cout + WG_BM - 1) / WG_BM;
+    const int t = tile / (n_mt * n_nt);
+    const int mt = (tile / n_nt) % n_mt, nt = tile % n_nt;
+    const int co0 = mt * WG_BM, ci0 = nt * WG_BN;
+    const int r_begin = blockIdx.x * a.rows_per_block;
+    const int r_end = min(a.out_rows, r_begin + a.rows_per_block);
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // loaders: G tile 32 rows x 128 couts = 1024 float4 -> 4 / thread; X tile 32 rows x 64 cins = 512 float4 -> 2 / thread
+    const int g_r = tid >> 5, g_c = (tid & 31) * 4;  // rows g_r + 8*p, p<4
+    const int x_r = tid >> 4, x_c = (tid & 15) * 4;  // rows x_r + 16*p, p<2
+    f32x4 rg[4], rx[2];
+    const int n_steps = (r_end - r_begin + WG_KB - 1) / WG_KB;
+    int any_next = 0;
+
+    auto load_tile = [&](int s) {
+        const int r0 = r_begin + s * WG_KB;
+        any_next = 0;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            int j = r0 + x_r + 16 * p;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            int src = (j < r_end) ? src_row_w(a, j, t) : -1;
+            if (src >= 0) {
+                any_next = 1;
+                if (ci0 + x_c < a.Cin) v = *reinterpret_cast<const f32x4 *>(a.in + (int64_t)src * a.Cin + ci0 + x_c);
+            }
+            rx[p] = v;
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            int j = r0 + g_r + 8 * p;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (j < r_end) {
+                int co = co0 + g_c;
+                const float *src = a.go + (int64_t)j * a.Cout + co;
+                if (co + 3 < a.Cout && (a.Cout & 3) == 0) v = *reinterpret_cast<const f32x4 *>(src);
+                else {
+                    if (co + 0 < a.Cout) v[0] = src[0];
+                    if (co + 1 < a.Cout) v[1] = src[1];
+                    if (co + 2 < a.Cout) v[2] = src[2];
+                    if (co + 3 < a.Cout) v[3] = src[3];
+                }
+            }
+            rg[p] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) *reinterpret_cast<f32x4 *>(&X_l[buf][x_r + 16 * p][x_c]) = rx[p];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(&G_l[buf][g_r + 8 * p][g_c]) = rg[p];
+        if (any_next) s_any[buf] = 1;
+    };
+
+    if (tid < 2) s_any[tid] = 0;
+    __syncthreads();
+    if (n_steps > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+    const int fr = lane & 31, fh = lane >> 5;
+    for (int s = 0; s < n_steps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < n_steps) load_tile(s + 1);
+        if (s_any[buf]) {  // block-uniform: skip K steps whose 32 rows have no source for this tap
+#pragma unroll
+            for (int kk = 0; kk < WG_KB / 2; ++kk) {
+                const int k = kk * 2 + fh;
+                float b = X_l[buf][k][wn * 32 + fr];
+                float a0 = G_l[buf][k][wm * 64 + fr];
+                float a1 = G_l[buf][k][wm * 64 + 32 + fr];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
+            }
+        }
+        __syncthreads();            // everyone done reading buf (and s_any[buf])
+        if (tid == 0) s_any[buf] = 0;
+        if (s + 1 < n_steps) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    // accumulate into grad_w[co][t][ci]
+    const int ci = ci0 + wn * 32 + fr;
+    if (ci < a.Cin) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                float v = acc[i][r];
+                if (co < a.Cout && v != 0.f) atomicAdd(&a.gw[((int64_t)co * a.taps + t) * a.Cin + ci], v);
+            }
+    }
+}
+
+extern "C" int rd_conv_wgrad(const float *in, int in_rows, int Cin, const float *grad_out, int out_rows, int Cout, int taps,
+                             const rd_conv_index *idx, float *grad_wk, void *stream) {
+    RD_REQUIRE(Cin > 0 && Cin % 32 == 0, "rd_conv_wgrad: Cin=%d must be a multiple of 32", Cin);
+    RD_REQUIRE(Cout > 0, "rd_conv_wgrad: bad Cout");
+    int rc = validate_index(idx, taps, in_rows, out_rows, "rd_conv_wgrad");
+    if (rc) return rc;
+    if (out_rows == 0) return RD_OK;
+    const int n_mt = (int)cdiv(Cout, WG_BM), n_nt = (int)cdiv(Cin, WG_BN);
+    const int tiles = taps * n_mt * n_nt;
+    // aim for ~2048 blocks, at least 256 rows per block
+    int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(cdiv(out_rows, 256), cdiv(2048, tiles)));
+    int rows_per_block = (int)(cdiv(cdiv(out_rows, chunks), WG_KB) * WG_KB);
+    chunks = cdiv(out_rows, rows_per_block);
+    WgradArgs a{in, in_rows, Cin, grad_out, out_rows, Cout, taps, *idx, grad_wk, rows_per_block};
+    dim3 grid((unsigned)chunks, (unsigned)tiles);
+    k_conv_wgrad<<<grid, 256, 0, S(stream)>>>(a);
+    return check_launch("rd_conv_wgrad");
+}
+
+// ---------------------------------------------------------------------------------------------- weight layouts
+__global__ void k_weight_layout(const float *src, float *dst, int Cout, int Cin, int taps, int kind, int flip) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)Cout * Cin * taps;
+    if (i >= total) return;
+    // i indexes the DESTINATION linearly
+    if (kind == 0) {  // [Cout][taps][Cin] -> same, optional tap flip
+        int c = (int)(i % Cin), t = (int)((i / Cin) % taps), n = (int)(i / ((int64_t)Cin * taps));
+        int ts = flip ? taps - 1 - t : t;
+        dst[i] = src[((int64_t)n * taps + ts) * Cin + c];
+    } else if (kind == 1) {  // torch conv [Cout][Cin][taps] -> [Cout][taps][Cin]
+        int c = (int)(i % Cin), t = (int)((i / Cin) % taps), n = (int)(i / ((int64_t)Cin * taps));
+        int ts = flip ? taps - 1 - t : t;
+        dst[i] = src[((int64_t)n * Cin + c) * taps + ts];
+    } else if (kind == 2) {  // kernel layout [Cout][taps][Cin] -> [Cin][taps][Cout]
+        int n = (int)(i % Cout), t = (int)((i / Cout) % taps), c = (int)(i / ((int64_t)Cout * taps));
+        int ts = flip ? taps - 1 - t : t;
+        dst[i] = src[((int64_t)n * taps + ts) * Cin + c];
+    } else if (kind == 3) {  // torch ConvTranspose2d [Cin][Cout][taps] -> [Cout][taps][Cin]
+        int c = (int)(i % Cin), t = (int)((i / Cin) % taps), n = (int)(i / ((int64_t)Cin * taps));
+        int ts = flip ? taps - 1 - t : t;
+        dst[i] = src[((int64_t)c * Cout + n) * taps + ts];
+    } else if (kind == 4) {  // [Cout][taps][Cin] -> torch conv [Cout][Cin][taps]
+        int t = (int)(i % taps), c = (int)((i / taps) % Cin), n = (int)(i / ((int64_t)Cin * taps));
+        int ts = flip ? taps - 1 - t : t;
+        dst[i] = src[((int64_t)n * taps + ts) * Cin + c];
+    } else if (kind == 5) {  // [Cout][taps][Cin] -> torch ConvTranspose2d [Cin][Cout][taps]
+        int t = (int)(i % taps), n = (int)((i / taps) % Cout), c = (int)(i / ((int64_t)Cout * taps));
+        int ts = flip ? taps - 1 - t : t;
+        dst[i] = src[((int64_t)n * taps + ts) * Cin + c];
+    }
+}
+
+extern "C" int rd_weight_layout(const float *src, float *dst, int Cout, int Cin, int taps, int kind, int flip, void *stream) {
+    RD_REQUIRE(kind >= 0 && kind <= 5, "rd_weight_layout: bad kind %d", kind);
+    int64_t total = (int64_t)Cout * Cin * taps;
+    if (total <= 0) return RD_OK;
+    k_weight_layout<<<cdiv(total, 256), 256, 0, S(stream)>>>(src, dst, Cout, Cin, taps, kind, flip);
+    return check_launch("rd_weight_layout");
+}

@@ -1,0 +1,279 @@
+// BatchNorm over rows (channels-last), fused affine + residual + activation, their backward, column sums, and the
+// sparse <-> dense row scatter.  See include/rdamd.h sections D and E.  All kernels are HBM-bound streaming passes:
+// float4 per lane, consecutive lanes on consecutive channels of a row (rows are contiguous, so a wave covers 1 KiB).
+// Reductions are two-stage and deterministic: per-block partial column sums, then one block adds the partials in
+// double precision in a fixed order.
+#include "common.hpp"
+
+using namespace rd;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RED_MAX_BLOCKS = 512;
+
+__device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * (1.f + erff(z * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad(float z) {
+    const float cdf = 0.5f * (1.f + erff(z * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * z * z);
+    return cdf + z * pdf;
+}
+
+// Generic column reduction: F(row, c) -> (v1, v2) per element; partial[block][2][C].
+template <class F>
+__global__ __launch_bounds__(256) void k_colreduce(int64_t rows, int C, F f, float *partial) {
+    extern __shared__ float sm[];  // [groups][2][C] staged reduction
+    const int tpr = C / 4;               // threads per row
+    const int groups = 256 / tpr > 0 ? 256 / tpr : 1;
+    const int tid = threadIdx.x;
+    if (tpr <= 256) {
+        const int g = tid / tpr, c4 = (tid % tpr) * 4;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        if (g < groups) {
+            for (int64_t r = (int64_t)blockIdx.x * groups + g; r < rows; r += (int64_t)gridDim.x * groups) {
+                f32x4 a, b;
+                f(r, c4, a, b);
+                s1 += a;
+                s2 += b;
+            }
+            float *dst = sm + (int64_t)g * 2 * C;
+            *reinterpret_cast<f32x4 *>(dst + c4) = s1;
+            *reinterpret_cast<f32x4 *>(dst + C + c4) = s2;
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * C; i += 256) {
+            float s = 0.f;
+            for (int q = 0; q < groups; ++q) s += sm[(int64_t)q * 2 * C + i];
+            partial[(int64_t)blockIdx.x * 2 * C + i] = s;
+        }
+    }
+}
+
+__global__ void k_colreduce_final(const float *partial, int n_blocks, int C2, float *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C2) return;
+    double s = 0.0;
+    for (int b = 0; b < n_blocks; ++b) s += (double)partial[(int64_t)b * C2 + i];
+    out[i] = (float)s;
+}
+
+template <class F>
+static int colreduce(int64_t rows, int C, F f, float *out2C, float *ws, int64_t ws_bytes, hipStream_t st, const char *who) {
+    RD_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "%s: C=%d must be a multiple of 4 in [4,1024]", who, C);
+    const int tpr = C / 4, groups = 256 / tpr;
+    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(RED_MAX_BLOCKS, cdiv(rows, (int64_t)groups * 8)));
+    RD_REQUIRE(ws_bytes >= (int64_t)blocks * 2 * C * 4, "%s: workspace too small (%lld < %lld)", who, (long long)ws_bytes,
+               (long long)blocks * 2 * C * 4);
+    size_t shm = (size_t)groups * 2 * C * 4;
+    k_colreduce<F><<<blocks, 256, shm, st>>>(rows, C, f, ws);
+    k_colreduce_final<<<cdiv(2 * C, 256), 256, 0, st>>>(ws, blocks, 2 * C, out2C);
+    return check_launch(who);
+}
+
+extern "C" int64_t rd_bn_bwd_ws_bytes(int64_t rows, int C) { return (int64_t)RED_MAX_BLOCKS * 2 * C * 4 + 2 * C * 4; }
+
+struct StatsF {
+    const float *x;
+    int C;
+    __device__ void operator()(int64_t r, int c, f32x4 &a, f32x4 &b) const {
+        a = *reinterpret_cast<const f32x4 *>(x + r * C + c);
+        b = a * a;
+    }
+};
+
+extern "C" int rd_bn_stats(const float *x, int64_t rows, int C, float *stats, float *ws, int64_t ws_bytes, void *stream) {
+    if (rows <= 0) {
+        RD_HIP(hipMemsetAsync(stats, 0, (size_t)2 * C * 4, S(stream)));
+        return RD_OK;
+    }
+    return colreduce(rows, C, StatsF{x, C}, stats, ws, ws_bytes, S(stream), "rd_bn_stats");
+}
+
+struct ColsumF {
+    const float *x;
+    int C;
+    __device__ void operator()(int64_t r, int c, f32x4 &a, f32x4 &b) const {
+        a = *reinterpret_cast<const f32x4 *>(x + r * C + c);
+        b = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+};
+__global__ void k_copy(const float *src, float *dst, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+extern "C" int rd_colsum(const float *x, int64_t rows, int C, float *out, float *ws, int64_t ws_bytes, void *stream) {
+    hipStream_t st = S(stream);
+    if (rows <= 0) {
+        RD_HIP(hipMemsetAsync(out, 0, (size_t)C * 4, st));
+        return RD_OK;
+    }
+    // ws layout: [2C result][partials]
+    RD_REQUIRE(ws_bytes >= (int64_t)2 * C * 4, "rd_colsum: workspace too small");
+    int rc = colreduce(rows, C, ColsumF{x, C}, ws, ws + 2 * C, ws_bytes - 2 * C * 4, st, "rd_colsum");
+    if (rc) return rc;
+    k_copy<<<cdiv(C, 256), 256, 0, st>>>(ws, out, C);
+    return check_launch("rd_colsum");
+}
+
+__global__ void k_bn_finalize(const float *stats, float n, int C, const float *gamma, const float *beta, float eps, float momentum,
+                              float *running_mean, float *running_var, float *mean_out, float *rstd_out, float *scale, float *shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double mean = (double)stats[c] / n;
+    double var = (double)stats[C + c] / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    float sc = g * rstd;
+    if (mean_out) mean_out[c] = (float)mean;
+    if (rstd_out) rstd_out[c] = rstd;
+    scale[c] = sc;
+    shift[c] = b - (float)mean * sc;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) {
+        double unbiased = n > 1.f ? var * n / (n - 1.0) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+extern "C" int rd_bn_finalize(const float *stats, int64_t rows, int C, const float *gamma, const float *beta, float eps, float momentum,
+                              float *running_mean, float *running_var, float *mean, float *rstd, float *scale, float *shift, void *stream) {
+    RD_REQUIRE(rows > 0, "rd_bn_finalize: BatchNorm over zero rows");
+    k_bn_finalize<<<cdiv(C, 256), 256, 0, S(stream)>>>(stats, (float)rows, C, gamma, beta, eps, momentum, running_mean, running_var, mean,
+                                                       rstd, scale, shift);
+    return check_launch("rd_bn_finalize");
+}
+
+__global__ void k_affine_act(const float *__restrict__ x, int64_t n4, int C, const float *__restrict__ scale, const float *__restrict__ shift,
+                             const float *__restrict__ residual, int act, float *__restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)((i * 4) % C);
+        f32x4 v = reinterpret_cast<const f32x4 *>(x)[i];
+        f32x4 sc = scale ? *reinterpret_cast<const f32x4 *>(scale + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+        f32x4 sh = shift ? *reinterpret_cast<const f32x4 *>(shift + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        v = v * sc + sh;
+        if (residual) v += reinterpret_cast<const f32x4 *>(residual)[i];
+        if (act == 1) {
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        } else if (act == 2) {
+            for (int k = 0; k < 4; ++k) v[k] = gelu_f(v[k]);
+        }
+        reinterpret_cast<f32x4 *>(y)[i] = v;
+    }
+}
+
+extern "C" int rd_affine_act(const float *x, int64_t rows, int C, const float *scale, const float *shift, const float *residual, int act,
+                             float *y, void *stream) {
+    RD_REQUIRE(C % 4 == 0, "rd_affine_act: C=%d must be a multiple of 4", C);
+    int64_t n4 = rows * C / 4;
+    if (n4 <= 0) return RD_OK;
+    int blocks = (int)std::min<int64_t>(cdiv(n4, 256), 4096);
+    k_affine_act<<<blocks, 256, 0, S(stream)>>>(x, n4, C, scale, shift, residual, act, y);
+    return check_launch("rd_affine_act");
+}
+
+// ---- backward of y = act(x*scale + shift [+ residual]) with train-mode batch statistics
+//   g' = grad_y * act'(.)          (relu: y > 0; gelu: derivative at z = x*scale + shift; residual excluded for gelu)
+//   dbeta = sum g', dgamma = sum g' * xhat, xhat = (x - mean) * rstd
+//   dx = gamma*rstd * (g' - dbeta/n - xhat * dgamma/n);  grad_residual = g'
+struct BnBwdF {
+    const float *x, *y, *gy, *mean, *rstd, *scale, *shift;
+    int C, act;
+    __device__ void operator()(int64_t r, int c, f32x4 &a, f32x4 &b) const {
+        f32x4 g = *reinterpret_cast<const f32x4 *>(gy + r * C + c);
+        f32x4 xv = *reinterpret_cast<const f32x4 *>(x + r * C + c);
+        if (act == 1) {
+            f32x4 yv = *reinterpret_cast<const f32x4 *>(y + r * C + c);
+            for (int k = 0; k < 4; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+        } else if (act == 2) {
+            for (int k = 0; k < 4; ++k) g[k] *= gelu_grad(fmaf(xv[k], scale[c + k], shift[c + k]));
+        }
+        f32x4 xh;
+        for (int k = 0; k < 4; ++k) xh[k] = (xv[k] - mean[c + k]) * rstd[c + k];
+        a = g;
+        b = g * xh;
+    }
+};
+
+__global__ void k_bn_bwd_apply(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ gy, int64_t n4, int C,
+                               const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ rstd,
+                               const float *__restrict__ scale, const float *__restrict__ shift, int act, const float *__restrict__ sums,
+                               float inv_n, float *__restrict__ gx, float *__restrict__ gres) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)((i * 4) % C);
+        f32x4 g = reinterpret_cast<const f32x4 *>(gy)[i];
+        f32x4 xv = reinterpret_cast<const f32x4 *>(x)[i];
+        if (act == 1) {
+            f32x4 yv = reinterpret_cast<const f32x4 *>(y)[i];
+            for (int k = 0; k < 4; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+        } else if (act == 2) {
+            for (int k = 0; k < 4; ++k) g[k] *= gelu_grad(fmaf(xv[k], scale[c + k], shift[c + k]));
+        }
+        if (gres) reinterpret_cast<f32x4 *>(gres)[i] = g;
+        f32x4 o;
+        for (int k = 0; k < 4; ++k) {
+            float xh = (xv[k] - mean[c + k]) * rstd[c + k];
+            float ga = gamma ? gamma[c + k] : 1.f;
+            o[k] = ga * rstd[c + k] * (g[k] - sums[c + k] * inv_n - xh * sums[C + c + k] * inv_n);
+        }
+        reinterpret_cast<f32x4 *>(gx)[i] = o;
+    }
+}
+
+__global__ void k_split2(const float *sums, int C, float *gbeta, float *ggamma) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (gbeta) gbeta[c] = sums[c];
+    if (ggamma) ggamma[c] = sums[C + c];
+}
+
+extern "C" int rd_bn_bwd(const float *x, const float *y, const float *grad_y, int64_t rows, int C, const float *gamma, const float *mean,
+                         const float *rstd, const float *scale, const float *shift, int act, int has_residual, float *grad_x,
+                         float *grad_res, float *grad_gamma, float *grad_beta, float *ws, int64_t ws_bytes, void *stream) {
+    RD_REQUIRE(rows > 0, "rd_bn_bwd: zero rows");
+    RD_REQUIRE(act >= 0 && act <= 2, "rd_bn_bwd: bad act");
+    RD_REQUIRE(!(act == 2 && has_residual), "rd_bn_bwd: gelu with residual is not supported");
+    RD_REQUIRE(ws_bytes >= rd_bn_bwd_ws_bytes(rows, C), "rd_bn_bwd: workspace too small");
+    hipStream_t st = S(stream);
+    float *sums = ws;  // [2C]: dbeta, dgamma
+    int rc = colreduce(rows, C, BnBwdF{x, y, grad_y, mean, rstd, scale, shift, C, act}, sums, ws + 2 * C, ws_bytes - 2 * C * 4, st, "rd_bn_bwd");
+    if (rc) return rc;
+    int64_t n4 = rows * C / 4;
+    int blocks = (int)std::min<int64_t>(cdiv(n4, 256), 4096);
+    k_bn_bwd_apply<<<blocks, 256, 0, st>>>(x, y, grad_y, n4, C, gamma, mean, rstd, scale, shift, act, sums, 1.0f / (float)rows, grad_x,
+                                           has_residual ? grad_res : nullptr);
+    k_split2<<<cdiv(C, 256), 256, 0, st>>>(sums, C, grad_beta, grad_gamma);
+    return check_launch("rd_bn_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------- sparse <-> dense
+__global__ void k_rows_to_dense(const float *__restrict__ feats, const int32_t *__restrict__ coords, int64_t n4, int C, int H, int W,
+                                float *__restrict__ dense, int to_dense) {
+    const int c4n = C / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i / c4n;
+        int c = (int)(i % c4n) * 4;
+        int b = coords[r * 3], y = coords[r * 3 + 1], x = coords[r * 3 + 2];
+        int64_t cell = ((int64_t)b * H + y) * W + x;
+        if (to_dense) *reinterpret_cast<f32x4 *>(dense + cell * C + c) = *reinterpret_cast<const f32x4 *>(feats + r * C + c);
+        else *reinterpret_cast<f32x4 *>(const_cast<float *>(feats) + r * C + c) = *reinterpret_cast<const f32x4 *>(dense + cell * C + c);
+    }
+}
+
+extern "C" int rd_rows_to_dense(const float *feats, const int32_t *coords, int n, int C, int batch, int H, int W, float *dense, void *stream) {
+    RD_REQUIRE(C % 4 == 0, "rd_rows_to_dense: C %% 4 != 0");
+    hipStream_t st = S(stream);
+    RD_HIP(hipMemsetAsync(dense, 0, (size_t)batch * H * W * C * 4, st));
+    int64_t n4 = (int64_t)n * C / 4;
+    if (n4 <= 0) return RD_OK;
+    k_rows_to_dense<<<(int)std::min<int64_t>(cdiv(n4, 256), 4096), 256, 0, st>>>(feats, coords, n4, C, H, W, dense, 1);
+    return check_launch("rd_rows_to_dense");
+}
+
+extern "C" int rd_dense_to_rows(const float *dense, const int32_t *coords, int n, int C, int batch, int H, int W, float *feats, void *stream) {
+    RD_REQUIRE(C % 4 == 0, "rd_dense_to_rows: C %% 4 != 0");
+    int64_t n4 = (int64_t)n * C / 4;
+    if (n4 <= 0) return RD_OK;
+    k_rows_to_dense<<<(int)std::min<int64_t>(cdiv(n4, 256), 4096), 256, 0, S(stream)>>>(feats, coords, n4, C, H, W, const_cast<float *>(dense), 0);
+    return check_launch("rd_dense_to_rows");
+}

@@ -1,0 +1,281 @@
+"""Thin Python callers of the C ABI (include/rdamd.h): torch is used only for device memory and streams.
+
+Every function takes CUDA tensors, validates shapes/dtypes on the host (a kernel fault can reset the
+whole GPU host), passes raw device pointers plus the current HIP stream, and raises RuntimeError on a
+non-zero return code.  No function here has a CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import native
+from .native import ConvIndex, check
+
+f32, i32 = torch.float32, torch.int32
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(t, dtype, name, dim=None):
+    if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise RuntimeError(f"{name}: expected contiguous CUDA {dtype} tensor, got device={t.device} dtype={t.dtype} "
+                           f"contiguous={t.is_contiguous()}")
+    if dim is not None and t.dim() != dim:
+        raise RuntimeError(f"{name}: expected {dim}-d tensor, got shape {tuple(t.shape)}")
+    return t
+
+
+# ------------------------------------------------------------------------------------------ index structures
+def rankgrid_alloc(n_cells, device):
+    nbytes = native.lib().rd_rankgrid_bytes(int(n_cells))
+    return torch.empty(nbytes // 4, dtype=i32, device=device)
+
+
+def rankgrid_count_tensor(rg, n_cells):
+    """0-d int32 view of the active-cell count word (device)."""
+    n_words = (int(n_cells) + 31) // 32
+    return rg[2 * n_words]
+
+
+def voxelize(points, batch, gx, gy, x0, y0, vx, vy):
+    _chk(points, f32, "points", 2)
+    n, nf = points.shape[0], points.shape[1] - 1
+    rg = rankgrid_alloc(batch * gx * gy, points.device)
+    point_row = torch.empty(n, dtype=i32, device=points.device)
+    check(native.lib().rd_voxelize(_p(points), n, nf, batch, gx, gy, x0, y0, vx, vy, _p(rg), _p(point_row), _stream()), "rd_voxelize")
+    return rg, point_row
+
+
+def rankgrid_coords(rg, batch, H, W, xmajor, n_rows):
+    coords = torch.empty((n_rows, 3), dtype=i32, device=rg.device)
+    check(native.lib().rd_rankgrid_coords(_p(rg), batch, H, W, int(xmajor), _p(coords), n_rows, _stream()), "rd_rankgrid_coords")
+    return coords
+
+
+def rankgrid_from_coords(coords, batch, H, W, xmajor):
+    _chk(coords, i32, "coords", 2)
+    rg = rankgrid_alloc(batch * H * W, coords.device)
+    check(native.lib().rd_rankgrid_from_coords(_p(coords), coords.shape[0], batch, H, W, int(xmajor), _p(rg), _stream()), "rd_rankgrid_from_coords")
+    return rg
+
+
+def rankgrid_downsample(in_coords, batch, Ho, Wo):
+    _chk(in_coords, i32, "in_coords", 2)
+    rg = rankgrid_alloc(batch * Ho * Wo, in_coords.device)
+    check(native.lib().rd_rankgrid_downsample(_p(in_coords), in_coords.shape[0], batch, Ho, Wo, _p(rg), _stream()), "rd_rankgrid_downsample")
+    return rg
+
+
+def nbr_subm(coords, rg, batch, H, W, xmajor):
+    n = coords.shape[0]
+    nbr = torch.empty((n, 9), dtype=i32, device=coords.device)
+    check(native.lib().rd_nbr_subm(_p(coords), n, _p(rg), batch, H, W, int(xmajor), _p(nbr), _stream()), "rd_nbr_subm")
+    return nbr
+
+
+def nbr_strided(out_coords, in_rg, batch, H, W, in_xmajor):
+    n = out_coords.shape[0]
+    nbr = torch.empty((n, 9), dtype=i32, device=out_coords.device)
+    check(native.lib().rd_nbr_strided(_p(out_coords), n, _p(in_rg), batch, H, W, int(in_xmajor), _p(nbr), _stream()), "rd_nbr_strided")
+    return nbr
+
+
+def nbr_strided_T(in_coords, out_rg, batch, Ho, Wo):
+    n = in_coords.shape[0]
+    nbrT = torch.empty((n, 9), dtype=i32, device=in_coords.device)
+    check(native.lib().rd_nbr_strided_T(_p(in_coords), n, _p(out_rg), batch, Ho, Wo, _p(nbrT), _stream()), "rd_nbr_strided_T")
+    return nbrT
+
+
+# ------------------------------------------------------------------------------------------ pillar VFE
+def vfe_pillar_mean(points, point_row, n_pillars):
+    acc = torch.empty((n_pillars, 4), dtype=f32, device=points.device)
+    check(native.lib().rd_vfe_pillar_mean(_p(points), points.shape[0], points.shape[1] - 1, _p(point_row), n_pillars, _p(acc), _stream()),
+          "rd_vfe_pillar_mean")
+    return acc
+
+
+def vfe_linear_stats(points, point_row, coords, acc, weight, geom):
+    stats = torch.empty(65, dtype=f32, device=points.device)
+    _chk(weight, f32, "vfe weight", 2)
+    if weight.shape != (32, 9 + points.shape[1] - 1):
+        raise RuntimeError(f"vfe weight shape {tuple(weight.shape)} != (32, {9 + points.shape[1] - 1})")
+    check(native.lib().rd_vfe_linear_stats(_p(points), points.shape[0], points.shape[1] - 1, _p(point_row), _p(coords), _p(acc), _p(weight),
+                                           _p(geom), _p(stats), _stream()), "rd_vfe_linear_stats")
+    return stats
+
+
+def vfe_linear_bn_relu_max(points, point_row, coords, acc, weight, geom, scale, shift, n_pillars, want_argmax):
+    if weight.shape != (32, 9 + points.shape[1] - 1):
+        raise RuntimeError(f"vfe weight shape {tuple(weight.shape)} != (32, {9 + points.shape[1] - 1})")
+    out = torch.empty((n_pillars, 32), dtype=f32, device=points.device)
+    argmax = torch.empty((n_pillars, 32), dtype=i32, device=points.device) if want_argmax else None
+    ws = torch.empty((n_pillars, 32), dtype=torch.int64, device=points.device)
+    check(native.lib().rd_vfe_linear_bn_relu_max(_p(points), points.shape[0], points.shape[1] - 1, _p(point_row), _p(coords), _p(acc),
+                                                 _p(_chk(weight, f32, "w")), _p(geom), _p(_chk(scale, f32, "scale")), _p(_chk(shift, f32, "shift")),
+                                                 n_pillars, _p(out), _p(argmax), _p(ws), _stream()), "rd_vfe_linear_bn_relu_max")
+    return out, argmax
+
+
+def vfe_backward(points, point_row, coords, acc, weight, geom, mean, rstd, gamma, beta, grad_out, argmax, n_valid):
+    n, nf = points.shape[0], points.shape[1] - 1
+    P = grad_out.shape[0]
+    gw = torch.empty_like(weight)
+    gg = torch.empty(32, dtype=f32, device=points.device)
+    gb = torch.empty(32, dtype=f32, device=points.device)
+    ws = torch.empty(max(n, 1) * 32 + 128, dtype=f32, device=points.device)
+    check(native.lib().rd_vfe_backward(_p(points), n, nf, _p(point_row), _p(coords), _p(acc), _p(weight), _p(geom), _p(mean), _p(rstd),
+                                       _p(gamma), _p(beta), _p(_chk(grad_out, f32, "grad_out", 2)), _p(argmax), P, int(n_valid),
+                                       _p(gw), _p(gg), _p(gb), _p(ws), _stream()), "rd_vfe_backward")
+    return gw, gg, gb
+
+
+# ------------------------------------------------------------------------------------------ convolution
+def conv_index_table(nbr, flip=False):
+    ix = ConvIndex()
+    ix.mode = 0
+    ix.nbr = nbr.data_ptr() if nbr is not None and nbr.numel() else None
+    ix.flip = int(flip)
+    return ix
+
+
+def conv_index_dense(B, Hin, Win, Hout, Wout, KH, KW, stride, pad, transposed=False):
+    ix = ConvIndex()
+    ix.mode = 2 if transposed else 1
+    ix.nbr = None
+    ix.B, ix.Hin, ix.Win, ix.Hout, ix.Wout = B, Hin, Win, Hout, Wout
+    ix.KH, ix.KW, ix.stride, ix.pad, ix.flip = KH, KW, stride, pad, 0
+    return ix
+
+
+def conv_fwd(x, weight_k, taps, bias, out_rows, Cout, ix, scale=None, shift=None, residual=None, relu=False, stats=None, nbr_keepalive=None):
+    """x (in_rows, Cin); weight_k (Cout, taps, Cin) kernel layout -> (out_rows, Cout)."""
+    _chk(x, f32, "conv input", 2)
+    _chk(weight_k, f32, "conv weight")
+    in_rows, Cin = x.shape
+    if weight_k.numel() != Cout * taps * Cin:
+        raise RuntimeError(f"conv weight has {weight_k.numel()} elements, expected {Cout}*{taps}*{Cin}")
+    if ix.mode == 0 and nbr_keepalive is not None:
+        if nbr_keepalive.shape != (out_rows, taps) or nbr_keepalive.dtype != i32 or not nbr_keepalive.is_contiguous():
+            raise RuntimeError(f"neighbour table shape {tuple(nbr_keepalive.shape)} != ({out_rows}, {taps})")
+    for t, nm, n in ((bias, "bias", Cout), (scale, "scale", Cout), (shift, "shift", Cout), (stats, "stats", 2 * Cout)):
+        if t is not None and (_chk(t, f32, nm).numel() != n):
+            raise RuntimeError(f"conv {nm}: {t.numel()} elements, expected {n}")
+    if residual is not None and (_chk(residual, f32, "residual").shape != (out_rows, Cout)):
+        raise RuntimeError("conv residual shape mismatch")
+    out = torch.empty((out_rows, Cout), dtype=f32, device=x.device)
+    check(native.lib().rd_conv_fwd(_p(x), in_rows, Cin, _p(weight_k), taps, _p(bias), _p(out), out_rows, Cout, ctypes.byref(ix),
+                                   _p(scale), _p(shift), _p(residual), int(relu), _p(stats), _stream()), "rd_conv_fwd")
+    return out
+
+
+def conv_wgrad(x, grad_out, taps, ix):
+    """-> grad weight in kernel layout (Cout, taps, Cin)."""
+    _chk(x, f32, "wgrad input", 2)
+    _chk(grad_out, f32, "wgrad grad_out", 2)
+    in_rows, Cin = x.shape
+    out_rows, Cout = grad_out.shape
+    gw = torch.zeros((Cout, taps, Cin), dtype=f32, device=x.device)
+    check(native.lib().rd_conv_wgrad(_p(x), in_rows, Cin, _p(grad_out), out_rows, Cout, taps, ctypes.byref(ix), _p(gw), _stream()), "rd_conv_wgrad")
+    return gw
+
+
+def weight_layout(src, Cout, Cin, taps, kind, flip=False, out_shape=None):
+    _chk(src, f32, "weight")
+    if src.numel() != Cout * Cin * taps:
+        raise RuntimeError("weight_layout: element count mismatch")
+    dst = torch.empty(out_shape if out_shape is not None else (Cout * Cin * taps,), dtype=f32, device=src.device)
+    check(native.lib().rd_weight_layout(_p(src), _p(dst), Cout, Cin, taps, kind, int(flip), _stream()), "rd_weight_layout")
+    return dst
+
+
+def _red_ws(rows, C, device):
+    nbytes = native.lib().rd_bn_bwd_ws_bytes(int(rows), int(C))
+    return torch.empty(nbytes // 4, dtype=f32, device=device), nbytes
+
+
+def colsum(x):
+    _chk(x, f32, "colsum input", 2)
+    rows, C = x.shape
+    out = torch.empty(C, dtype=f32, device=x.device)
+    if C % 4 != 0:       # tiny heads (1..3 channels): not worth a kernel variant
+        raise RuntimeError("colsum: C must be a multiple of 4")
+    ws, nb = _red_ws(rows, C, x.device)
+    check(native.lib().rd_colsum(_p(x), rows, C, _p(out), _p(ws), nb, _stream()), "rd_colsum")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ batch norm
+def bn_stats(x):
+    _chk(x, f32, "bn input", 2)
+    rows, C = x.shape
+    stats = torch.empty(2 * C, dtype=f32, device=x.device)
+    ws, nb = _red_ws(rows, C, x.device)
+    check(native.lib().rd_bn_stats(_p(x), rows, C, _p(stats), _p(ws), nb, _stream()), "rd_bn_stats")
+    return stats
+
+
+def bn_finalize(stats, rows, C, gamma, beta, eps, momentum, running_mean, running_var):
+    dev = stats.device
+    mean = torch.empty(C, dtype=f32, device=dev)
+    rstd = torch.empty(C, dtype=f32, device=dev)
+    scale = torch.empty(C, dtype=f32, device=dev)
+    shift = torch.empty(C, dtype=f32, device=dev)
+    check(native.lib().rd_bn_finalize(_p(stats), rows, C, _p(gamma), _p(beta), eps, momentum, _p(running_mean), _p(running_var),
+                                      _p(mean), _p(rstd), _p(scale), _p(shift), _stream()), "rd_bn_finalize")
+    return mean, rstd, scale, shift
+
+
+def affine_act(x, scale, shift, residual, act):
+    _chk(x, f32, "affine input", 2)
+    rows, C = x.shape
+    y = torch.empty_like(x)
+    if residual is not None:
+        _chk(residual, f32, "residual", 2)
+        if residual.shape != x.shape:
+            raise RuntimeError("affine_act: residual shape mismatch")
+    check(native.lib().rd_affine_act(_p(x), rows, C, _p(scale), _p(shift), _p(residual), act, _p(y), _stream()), "rd_affine_act")
+    return y
+
+
+def bn_bwd(x, y, grad_y, gamma, mean, rstd, scale, shift, act, has_residual):
+    _chk(x, f32, "x", 2); _chk(grad_y, f32, "grad_y", 2)
+    rows, C = x.shape
+    if grad_y.shape != x.shape or (y is not None and y.shape != x.shape):
+        raise RuntimeError("bn_bwd: shape mismatch")
+    gx = torch.empty_like(x)
+    gres = torch.empty_like(x) if has_residual else None
+    gg = torch.empty(C, dtype=f32, device=x.device)
+    gb = torch.empty(C, dtype=f32, device=x.device)
+    ws, nb = _red_ws(rows, C, x.device)
+    check(native.lib().rd_bn_bwd(_p(x), _p(y), _p(grad_y), rows, C, _p(gamma), _p(mean), _p(rstd), _p(scale), _p(shift), act,
+                                 int(has_residual), _p(gx), _p(gres), _p(gg), _p(gb), _p(ws), nb, _stream()), "rd_bn_bwd")
+    return gx, gres, gg, gb
+
+
+# ------------------------------------------------------------------------------------------ sparse <-> dense
+def rows_to_dense(feats, coords, batch, H, W):
+    _chk(feats, f32, "feats", 2); _chk(coords, i32, "coords", 2)
+    n, C = feats.shape
+    if coords.shape != (n, 3):
+        raise RuntimeError("rows_to_dense: coords shape mismatch")
+    dense = torch.empty((batch * H * W, C), dtype=f32, device=feats.device)
+    check(native.lib().rd_rows_to_dense(_p(feats), _p(coords), n, C, batch, H, W, _p(dense), _stream()), "rd_rows_to_dense")
+    return dense
+
+
+def dense_to_rows(dense, coords, batch, H, W):
+    _chk(dense, f32, "dense", 2); _chk(coords, i32, "coords", 2)
+    C = dense.shape[1]
+    n = coords.shape[0]
+    if dense.shape[0] != batch * H * W:
+        raise RuntimeError("dense_to_rows: dense shape mismatch")
+    feats = torch.empty((n, C), dtype=f32, device=dense.device)
+    check(native.lib().rd_dense_to_rows(_p(dense), _p(coords), n, C, batch, H, W, _p(feats), _stream()), "rd_dense_to_rows")
+    return feats

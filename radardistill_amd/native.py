@@ -1,0 +1,130 @@
+"""ctypes binding of librdamd.so (the C ABI declared in include/rdamd.h).
+
+The library is built in-tree by `build()` (hipcc, gfx950 only) and loaded lazily by `lib()`.
+There is NO fallback: if the shared object is missing or a call returns non-zero, a RuntimeError is
+raised (the reference ops raise c10::Error, pcdet/ops/basicblock/src/cuda/modulated_deform_conv_cuda.cu:39-73).
+"""
+import ctypes
+import glob
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "librdamd.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "rdamd.h")
+
+c_int, c_i64, c_f32, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+
+class ConvIndex(ctypes.Structure):
+    """rd_conv_index of include/rdamd.h."""
+    _fields_ = [("mode", c_int), ("nbr", c_vp), ("B", c_int), ("Hin", c_int), ("Win", c_int), ("Hout", c_int),
+                ("Wout", c_int), ("KH", c_int), ("KW", c_int), ("stride", c_int), ("pad", c_int), ("flip", c_int)]
+
+
+# name -> (restype, argtypes).  Must list EVERY symbol declared in include/rdamd.h (tests check this).
+_P = c_vp
+SIGNATURES = {
+    "rd_last_error": (ctypes.c_char_p, []),
+    "rd_abi_version": (c_int, []),
+    "rd_device_ok": (c_int, []),
+    "rd_rankgrid_bytes": (c_i64, [c_i64]),
+    "rd_voxelize": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_f32, c_f32, c_f32, c_f32, _P, _P, _P]),
+    "rd_rankgrid_coords": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    "rd_rankgrid_from_coords": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "rd_rankgrid_downsample": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    "rd_nbr_subm": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "rd_nbr_strided": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "rd_nbr_strided_T": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, _P]),
+    "rd_vfe_pillar_mean": (c_int, [_P, c_int, c_int, _P, c_int, _P, _P]),
+    "rd_vfe_linear_stats": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "rd_vfe_linear_bn_relu_max": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
+    "rd_vfe_backward": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
+    "rd_conv_fwd": (c_int, [_P, c_int, c_int, _P, c_int, _P, _P, c_int, c_int, ctypes.POINTER(ConvIndex), _P, _P, _P, c_int, _P, _P]),
+    "rd_conv_wgrad": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, ctypes.POINTER(ConvIndex), _P, _P]),
+    "rd_weight_layout": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "rd_colsum": (c_int, [_P, c_i64, c_int, _P, _P, c_i64, _P]),
+    "rd_bn_stats": (c_int, [_P, c_i64, c_int, _P, _P, c_i64, _P]),
+    "rd_bn_finalize": (c_int, [_P, c_i64, c_int, _P, _P, c_f32, c_f32, _P, _P, _P, _P, _P, _P, _P]),
+    "rd_affine_act": (c_int, [_P, c_i64, c_int, _P, _P, _P, c_int, _P, _P]),
+    "rd_bn_bwd_ws_bytes": (c_i64, [c_i64, c_int]),
+    "rd_bn_bwd": (c_int, [_P, _P, _P, c_i64, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, c_i64, _P]),
+    "rd_rows_to_dense": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "rd_dense_to_rows": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+}
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _stale():
+    if not os.path.exists(SO_PATH):
+        return True
+    t = os.path.getmtime(SO_PATH)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + [HEADER]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into csrc/librdamd.so (hipcc cross-compiles without a GPU)."""
+    if not force and not _stale():
+        return SO_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(CSRC, "obj"), exist_ok=True)
+    for src in sources():
+        obj = os.path.join(CSRC, "obj", os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(
+                os.path.getmtime(src), os.path.getmtime(HEADER), os.path.getmtime(os.path.join(CSRC, "common.hpp"))):
+            continue
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO_PATH] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout.decode(errors='replace')}")
+    return SO_PATH
+
+
+_LIB = None
+
+
+def lib():
+    """The loaded library with typed entry points.  Raises if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                f"{SO_PATH} is missing: the HIP extension has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'`).  There is no CPU fallback.")
+        L = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError here == header/library mismatch: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().rd_last_error()
+        raise RuntimeError(f"librdamd {what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def header_symbols():
+    """Function names declared in include/rdamd.h (used by the CPU test that the library exports them all)."""
+    import re
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rd_[A-Za-z0-9_]+)\s*\(", text)))

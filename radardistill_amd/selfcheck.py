@@ -1,0 +1,43 @@
+"""smoke(): one tiny hot-path invocation on cuda:0 compared with the CPU oracle (the oracle is imported here only as the
+checker, as the task's layout rules allow for __graft_entry__.smoke())."""
+import numpy as np
+import torch
+
+
+def smoke_check():
+    from oracle import sparse as osp, vfe as ovfe          # checker only
+    from .pcdet.config import AttrDict
+    from .pcdet.models.backbones_3d import __all__ as B3
+    from .pcdet.models.backbones_3d.vfe import __all__ as VFE
+    from .synthetic import bench_geometry, make_batch
+    dev = "cuda:0"
+    grid, B = 128, 2
+    pc_range, voxel, gs = bench_geometry(grid)
+    cfg = AttrDict(WITH_DISTANCE=False, USE_ABSLOTE_XYZ=True, USE_CLUSTER_XYZ=True, USE_NORM=True, NUM_FILTERS=[32])
+    torch.manual_seed(0)
+    vfe_m = VFE["Radar_DynamicPillarVFESimple2D"](model_cfg=cfg, num_point_features=6, voxel_size=voxel, grid_size=gs,
+                                                  point_cloud_range=pc_range).to(dev)
+    bb = B3["Radar_PillarRes18BackBone8x"](None, 32, gs).to(dev)
+    batch = make_batch(batch_size=B, n_lidar=16, n_radar=1000, n_boxes=2, grid=grid, seed=0)
+    pts = torch.from_numpy(batch["radar_points"])
+    vfe_m.train(); bb.train()
+    st = {("v." + k): v.detach().cpu().clone() for k, v in vfe_m.state_dict().items()}
+    st.update({("b." + k): v.detach().cpu().clone() for k, v in bb.state_dict().items()})
+    bd = bb(vfe_m({"radar_points": pts.to(dev), "batch_size": B}))
+    x5 = bd["radar_multi_scale_2d_features"]["x_conv5"]
+    x5.square().mean().backward()
+    torch.cuda.synchronize()
+    for k in st:
+        if st[k].is_floating_point() and "running" not in k:
+            st[k].requires_grad_(True)
+    ov = ovfe.dynamic_pillar_vfe(pts, st, "v.", pc_range, voxel, gs, training=True)
+    ob = osp.pillar_res18_backbone(ov["pillar_features"], ov["pillar_coords"].numpy(), B, gs, st, "b.", training=True)
+    ob["x_conv5"].square().mean().backward()
+    assert np.array_equal(bd["radar_pillar_coords"].cpu().numpy(), ov["pillar_coords"].numpy()), "pillar indices differ"
+    err = float((x5.detach().cpu() - ob["x_conv5"].detach()).abs().max()) / (float(ob["x_conv5"].abs().max()) + 1e-6)
+    assert err < 1e-3, f"x_conv5 relative error {err}"
+    g_hip = bb.conv1[0].conv1.weight.grad.cpu()
+    g_ref = st["b.conv1.0.conv1.weight"].grad
+    gerr = float((g_hip - g_ref).abs().max()) / (float(g_ref.abs().max()) + 1e-12)
+    assert gerr < 2e-3, f"first-layer weight gradient relative error {gerr}"
+    print(f"smoke: x_conv5 rel err {err:.2e}, conv1 wgrad rel err {gerr:.2e}")

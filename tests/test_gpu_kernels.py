@@ -1,0 +1,336 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every HIP kernel through the C ABI vs the CPU oracle / torch-CPU.
+Tolerance: bit-exact for indices / rulebooks; rtol 1e-3 (north_star) for fp32 features and gradients."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import sparse as osp, vfe as ovfe            # noqa: E402  (checker only)
+from radardistill_amd.synthetic import bench_geometry, make_batch   # noqa: E402
+from tests.seeded import seeded_fill_                    # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _mods():
+    from radardistill_amd import autograd as A, kernels as K, sparse as SP
+    return A, K, SP
+
+
+def close(a, b, rtol=1e-3, atol=1e-4, what=""):
+    a = a.detach().float().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().float().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    scale = max(1.0, float(np.abs(b).max())) if b.size else 1.0
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol * scale, err_msg=what)
+
+
+def rand_sites(rng, B, H, W, n):
+    keys = np.sort(rng.choice(B * H * W, size=n, replace=False))
+    return np.stack([keys // (H * W), (keys // W) % H, keys % W], axis=1).astype(np.int32)
+
+
+def test_library_reports_gfx950():
+    from radardistill_amd import native
+    assert native.lib().rd_device_ok() == 1
+
+
+@pytest.mark.parametrize("H,W,n", [(64, 48, 500), (33, 31, 200), (16, 16, 0), (8, 8, 128)])
+def test_rulebooks_bit_exact(H, W, n):
+    A, K, SP = _mods()
+    rng = np.random.default_rng(H * 1000 + n)
+    B = 3
+    idx = rand_sites(rng, B, H, W, n)
+    coords = torch.from_numpy(idx).to(DEV)
+    t = SP.SparseConvTensor(torch.zeros((n, 32), device=DEV), coords, [H, W], B)
+    nbr = t._level.subm_spec().fwd_nbr if n else None
+    ref = osp.subm_rulebook(idx, (H, W))
+    if n:
+        assert np.array_equal(nbr.cpu().numpy(), ref)
+    lvl, spec = t._level.down()
+    oidx, oshape, snbr = osp.strided_rulebook(idx, (H, W))
+    assert (lvl.H, lvl.W) == tuple(oshape)
+    assert np.array_equal(lvl.coords.cpu().numpy(), oidx)            # canonical (b,y,x)-sorted output sites
+    if oidx.shape[0]:
+        assert np.array_equal(spec.fwd_nbr.cpu().numpy(), snbr)
+        # transposed table: nbrT[i][t] == o  <=>  nbr[o][t] == i
+        nbrT = spec.bwd_nbr.cpu().numpy()
+        exp = -np.ones_like(nbrT)
+        o, tt = np.nonzero(snbr >= 0)
+        exp[snbr[o, tt], tt] = o
+        assert np.array_equal(nbrT, exp)
+
+
+def test_rulebook_xmajor_order_matches_voxelizer():
+    """pillar rows come in (b, cx, cy) key order; lookups must honour that linearisation."""
+    A, K, SP = _mods()
+    rng = np.random.default_rng(5)
+    B, H, W = 2, 40, 24
+    idx = rand_sites(rng, B, H, W, 300)
+    order = np.lexsort((idx[:, 1], idx[:, 2], idx[:, 0]))           # sort by (b, x, y)
+    idx_x = idx[order]
+    t = SP.SparseConvTensor(torch.zeros((300, 32), device=DEV), torch.from_numpy(idx_x).to(DEV), [H, W], B)
+    assert t._level.xmajor
+    assert np.array_equal(t._level.subm_spec().fwd_nbr.cpu().numpy(), osp.subm_rulebook(idx_x, (H, W)))
+    lvl, spec = t._level.down()
+    oidx, _, snbr = osp.strided_rulebook(idx_x, (H, W))
+    assert np.array_equal(lvl.coords.cpu().numpy(), oidx) and np.array_equal(spec.fwd_nbr.cpu().numpy(), snbr)
+
+
+def _vfe_module(tag, nfeat, grid, seed=11):
+    from radardistill_amd.pcdet.models.backbones_3d.vfe import __all__ as REG
+    from radardistill_amd.pcdet.config import AttrDict
+    pc_range, voxel, gs = bench_geometry(grid)
+    cfg = AttrDict(WITH_DISTANCE=False, USE_ABSLOTE_XYZ=True, USE_CLUSTER_XYZ=True, USE_NORM=True, NUM_FILTERS=[32])
+    name = "Radar_DynamicPillarVFESimple2D" if tag == "radar" else "DynamicPillarVFESimple2D"
+    m = REG[name](model_cfg=cfg, num_point_features=nfeat, voxel_size=voxel, grid_size=gs, point_cloud_range=pc_range)
+    sd = m.state_dict(); seeded_fill_(sd, seed=seed); m.load_state_dict(sd)
+    return m.to(DEV), pc_range, voxel, gs
+
+
+@pytest.mark.parametrize("tag,key,nfeat", [("radar", "radar_points", 6), ("lidar", "points", 5)])
+def test_vfe_golden_from_reference(golden_dir, tag, key, nfeat):
+    """HIP VFE vs the fixture produced by the reference's own module (tests/golden/make_golden.py:g1_vfe)."""
+    g = np.load(f"{golden_dir}/g1_vfe.npz")
+    m, pc_range, voxel, gs = _vfe_module(tag, nfeat, 128)
+    batch = make_batch(batch_size=2, n_lidar=2000, n_radar=1000, n_boxes=4, grid=128, seed=1)
+    pts = torch.from_numpy(batch[key]).clone()
+    pts[:5, 1] = torch.tensor([pc_range[3] + 0.05, pc_range[0] - 0.01, pc_range[3], pc_range[0], 0.0])
+    pre = "radar_" if tag == "radar" else ""
+    for mode in ("eval", "train"):
+        m.train(mode == "train")
+        with torch.no_grad():
+            bd = m({key: pts.to(DEV), "batch_size": 2})
+        assert np.array_equal(bd[pre + "pillar_coords"].cpu().numpy(), g[f"{tag}_{mode}_coords"])   # bit-exact
+        close(bd[pre + "pillar_features"], g[f"{tag}_{mode}_features"], what=f"{tag} {mode}")
+    close(m.pfn_layers[0].norm.running_mean, g[f"{tag}_running_mean_after"])
+    close(m.pfn_layers[0].norm.running_var, g[f"{tag}_running_var_after"])
+
+
+def test_vfe_backward_vs_oracle():
+    m, pc_range, voxel, gs = _vfe_module("radar", 6, 128, seed=3)
+    batch = make_batch(batch_size=2, n_lidar=16, n_radar=1500, n_boxes=1, grid=128, seed=7)
+    pts = torch.from_numpy(batch["radar_points"])
+    m.train()
+    bd = m({"radar_points": pts.to(DEV), "batch_size": 2})
+    f = bd["radar_pillar_features"]
+    gw = torch.from_numpy(np.random.default_rng(0).normal(size=tuple(f.shape)).astype(np.float32))
+    (f * gw.to(DEV)).sum().backward()
+    st = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    seeded_fill_(st, seed=3)
+    for k in ("pfn_layers.0.linear.weight", "pfn_layers.0.norm.weight", "pfn_layers.0.norm.bias"):
+        st[k].requires_grad_(True)
+    out = ovfe.dynamic_pillar_vfe(pts, st, "", pc_range, voxel, gs, training=True)
+    close(f, out["pillar_features"])
+    (out["pillar_features"] * gw).sum().backward()
+    close(m.pfn_layers[0].linear.weight.grad, st["pfn_layers.0.linear.weight"].grad, atol=2e-4)
+    close(m.pfn_layers[0].norm.weight.grad, st["pfn_layers.0.norm.weight"].grad, atol=2e-4)
+    close(m.pfn_layers[0].norm.bias.grad, st["pfn_layers.0.norm.bias"].grad, atol=2e-4)
+
+
+def test_vfe_empty_and_all_outside():
+    m, pc_range, voxel, gs = _vfe_module("radar", 6, 128)
+    m.eval()
+    pts = torch.zeros((10, 7)); pts[:, 1] = 1e4                      # every point outside the range
+    bd = m({"radar_points": pts.to(DEV), "batch_size": 1})
+    assert bd["radar_pillar_features"].shape == (0, 32) and bd["radar_pillar_coords"].shape == (0, 3)
+    bd = m({"radar_points": torch.zeros((0, 7), device=DEV), "batch_size": 1})
+    assert bd["radar_pillar_features"].shape == (0, 32)
+
+
+@pytest.mark.parametrize("Cin,Cout", [(32, 32), (64, 128), (128, 256), (32, 27), (256, 3)])
+def test_sparse_conv_forward_and_backward(Cin, Cout):
+    A, K, SP = _mods()
+    rng = np.random.default_rng(Cin + Cout)
+    B, H, W, n = 2, 40, 36, 700
+    idx = rand_sites(rng, B, H, W, n)
+    feats = torch.from_numpy(rng.normal(size=(n, Cin)).astype(np.float32))
+    w = torch.from_numpy((rng.normal(size=(Cout, 3, 3, Cin)) / np.sqrt(9 * Cin)).astype(np.float32))
+    b = torch.from_numpy(rng.normal(size=(Cout,)).astype(np.float32))
+    for subm in (True, False):
+        conv = (SP.SubMConv2d if subm else SP.SparseConv2d)(Cin, Cout, 3, stride=1 if subm else 2, padding=1, bias=True).to(DEV)
+        with torch.no_grad():
+            conv.weight.copy_(w); conv.bias.copy_(b)
+        fd = feats.to(DEV).requires_grad_(True)
+        t = SP.SparseConvTensor(fd, torch.from_numpy(idx).to(DEV), [H, W], B)
+        out = conv(t)
+        fr = feats.clone().requires_grad_(True); wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+        if subm:
+            nbr = osp.subm_rulebook(idx, (H, W))
+        else:
+            oidx, _, nbr = osp.strided_rulebook(idx, (H, W))
+            assert np.array_equal(out.indices.cpu().numpy(), oidx)
+        ref = osp.sparse_conv(fr, nbr, wr, br)
+        close(out.features, ref, what=f"fwd subm={subm}")
+        go = torch.from_numpy(rng.normal(size=tuple(ref.shape)).astype(np.float32))
+        (out.features * go.to(DEV)).sum().backward()
+        (ref * go).sum().backward()
+        close(fd.grad, fr.grad, what="dgrad")
+        close(conv.weight.grad, wr.grad, atol=2e-4, what="wgrad")
+        close(conv.bias.grad, br.grad, atol=2e-4, what="bias grad")
+
+
+@pytest.mark.parametrize("Cin,Cout,k,s,p,H,W", [(256, 256, 3, 1, 1, 12, 10), (256, 256, 3, 2, 1, 13, 11), (512, 256, 1, 1, 0, 9, 9),
+                                                 (64, 2, 3, 1, 1, 8, 8), (256, 27, 3, 2, 1, 16, 16)])
+def test_dense_conv2d_forward_and_backward(Cin, Cout, k, s, p, H, W):
+    A, K, SP = _mods()
+    rng = np.random.default_rng(Cin * 7 + Cout + k)
+    B = 2
+    x = torch.from_numpy(rng.normal(size=(B, Cin, H, W)).astype(np.float32))
+    conv = torch.nn.Conv2d(Cin, Cout, k, s, p, bias=True)
+    xr = x.clone().requires_grad_(True)
+    ref = conv(xr)
+    go = torch.from_numpy(rng.normal(size=tuple(ref.shape)).astype(np.float32))
+    (ref * go).sum().backward()
+    import copy
+    cd = copy.deepcopy(conv).to(DEV)
+    cd.weight.grad = None; cd.bias.grad = None
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    rows, _, _, _ = A.nchw_to_rows(xd)
+    spec = A.dense_conv_spec(B, H, W, k, k, s, p)
+    out = A.rows_to_nchw(A.conv(rows, cd.weight, cd.bias, spec, Cout), B, *spec.out_hw)
+    close(out, ref, what="conv2d fwd")
+    (out * go.to(DEV)).sum().backward()
+    close(xd.grad, xr.grad, what="conv2d dgrad")
+    close(cd.weight.grad, conv.weight.grad, atol=2e-4, what="conv2d wgrad")
+    close(cd.bias.grad, conv.bias.grad, atol=2e-4, what="conv2d bias grad")
+
+
+@pytest.mark.parametrize("k,s,p", [(2, 2, 0), (4, 2, 1)])
+def test_conv_transpose2d_forward_and_backward(k, s, p):
+    A, K, SP = _mods()
+    rng = np.random.default_rng(k)
+    B, C, H, W = 2, 256, 7, 6
+    x = torch.from_numpy(rng.normal(size=(B, C, H, W)).astype(np.float32))
+    m = torch.nn.ConvTranspose2d(C, C, k, s, p, bias=True)
+    xr = x.clone().requires_grad_(True)
+    ref = m(xr)
+    go = torch.from_numpy(rng.normal(size=tuple(ref.shape)).astype(np.float32))
+    (ref * go).sum().backward()
+    import copy
+    md = copy.deepcopy(m).to(DEV); md.weight.grad = None; md.bias.grad = None
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    rows, _, _, _ = A.nchw_to_rows(xd)
+    spec = A.dense_conv_spec(B, H, W, k, k, s, p, transposed=True)
+    assert tuple(spec.out_hw) == tuple(ref.shape[2:])
+    out = A.rows_to_nchw(A.conv(rows, md.weight, md.bias, spec, C), B, *spec.out_hw)
+    close(out, ref, what="convT fwd")
+    (out * go.to(DEV)).sum().backward()
+    close(xd.grad, xr.grad, what="convT dgrad")
+    close(md.weight.grad, m.weight.grad, atol=2e-4, what="convT wgrad")
+
+
+def test_linear_as_one_tap_conv():
+    A, K, SP = _mods()
+    rng = np.random.default_rng(9)
+    x = torch.from_numpy(rng.normal(size=(333, 256)).astype(np.float32))
+    lin = torch.nn.Linear(256, 1024)
+    xr = x.clone().requires_grad_(True); ref = lin(xr)
+    go = torch.from_numpy(rng.normal(size=tuple(ref.shape)).astype(np.float32)); (ref * go).sum().backward()
+    import copy
+    ld = copy.deepcopy(lin).to(DEV); ld.weight.grad = None; ld.bias.grad = None
+    xd = x.to(DEV).requires_grad_(True)
+    out = A.conv(xd, ld.weight, ld.bias, A.linear_spec(333), 1024)
+    close(out, ref); (out * go.to(DEV)).sum().backward()
+    close(xd.grad, xr.grad); close(ld.weight.grad, lin.weight.grad, atol=2e-4); close(ld.bias.grad, lin.bias.grad, atol=2e-4)
+
+
+def test_conv_epilogue_and_fused_stats():
+    A, K, SP = _mods()
+    rng = np.random.default_rng(21)
+    rows, Cin, Cout = 1000, 64, 64
+    x = torch.from_numpy(rng.normal(size=(rows, Cin)).astype(np.float32))
+    w = torch.from_numpy((rng.normal(size=(Cout, Cin)) / 8).astype(np.float32))
+    b, sc, sh = [torch.from_numpy(rng.normal(size=(Cout,)).astype(np.float32)) for _ in range(3)]
+    res = torch.from_numpy(rng.normal(size=(rows, Cout)).astype(np.float32))
+    spec = A.linear_spec(rows)
+    out = K.conv_fwd(x.to(DEV), w.to(DEV).view(Cout, 1, Cin), 1, b.to(DEV), rows, Cout, spec.fwd_ix, scale=sc.to(DEV), shift=sh.to(DEV),
+                     residual=res.to(DEV), relu=True)
+    pre = x @ w.t() + b
+    close(out, torch.relu(pre * sc + sh + res))
+    stats = torch.zeros(2 * Cout, device=DEV)
+    K.conv_fwd(x.to(DEV), w.to(DEV).view(Cout, 1, Cin), 1, b.to(DEV), rows, Cout, spec.fwd_ix, stats=stats)
+    close(stats[:Cout], pre.sum(0), atol=2e-4); close(stats[Cout:], (pre * pre).sum(0), atol=2e-4)
+
+
+@pytest.mark.parametrize("C,rows,act,res", [(32, 5000, 1, True), (256, 777, 1, False), (256, 1000, 2, False), (64, 300, 0, False)])
+def test_batchnorm_train_forward_backward(C, rows, act, res):
+    A, K, SP = _mods()
+    rng = np.random.default_rng(C + rows)
+    x = torch.from_numpy((rng.normal(size=(rows, C)) * 2 + 0.5).astype(np.float32))
+    r = torch.from_numpy(rng.normal(size=(rows, C)).astype(np.float32)) if res else None
+    bn = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.01)
+    with torch.no_grad():
+        bn.weight.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, C).astype(np.float32)))
+        bn.bias.copy_(torch.from_numpy(rng.normal(size=C).astype(np.float32)))
+    import copy
+    bd = copy.deepcopy(bn).to(DEV)
+    xr = x.clone().requires_grad_(True); rr = r.clone().requires_grad_(True) if res else None
+    z = bn(xr) + (rr if res else 0)
+    ref = torch.relu(z) if act == 1 else (F.gelu(z) if act == 2 else z)
+    go = torch.from_numpy(rng.normal(size=(rows, C)).astype(np.float32)); (ref * go).sum().backward()
+    xd = x.to(DEV).requires_grad_(True); rd = r.to(DEV).requires_grad_(True) if res else None
+    out = A.bn_act_train(xd, bd, rd, act=act)
+    close(out, ref); (out * go.to(DEV)).sum().backward()
+    close(xd.grad, xr.grad, atol=2e-4); close(bd.weight.grad, bn.weight.grad, atol=2e-4); close(bd.bias.grad, bn.bias.grad, atol=2e-4)
+    if res:
+        close(rd.grad, rr.grad)
+    close(bd.running_mean, bn.running_mean); close(bd.running_var, bn.running_var)
+    assert int(bd.num_batches_tracked) == 1
+
+
+def _backbone(prefix_radar, grid, seed):
+    from radardistill_amd.pcdet.models.backbones_3d import __all__ as REG
+    m = REG["Radar_PillarRes18BackBone8x" if prefix_radar else "PillarRes18BackBone8x"](None, 32, np.array([grid, grid, 40]))
+    sd = m.state_dict(); seeded_fill_(sd, seed=seed); m.load_state_dict(sd)
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_sparse_enc_c2_vs_oracle(training):
+    """BASELINE config C2 at reduced size: radar VFE + SparseEnc (+dense(), conv5): indices bit-exact, features 1e-3."""
+    grid, B = 128, 2
+    vfe_m, pc_range, voxel, gs = _vfe_module("radar", 6, grid, seed=31)
+    bb = _backbone(True, grid, seed=32)
+    vfe_m.train(training); bb.train(training)
+    batch = make_batch(batch_size=B, n_lidar=16, n_radar=1200, n_boxes=2, grid=grid, seed=11)
+    pts = torch.from_numpy(batch["radar_points"])
+    bd = {"radar_points": pts.to(DEV), "batch_size": B}
+    with torch.set_grad_enabled(training):
+        bd = bb(vfe_m(bd))
+    ms = bd["radar_multi_scale_2d_features"]
+    st = {("radar_vfe." + k): v.detach().cpu().clone() for k, v in vfe_m.state_dict().items()}
+    st.update({("radar_backbone_3d." + k): v.detach().cpu().clone() for k, v in bb.state_dict().items()})
+    seeded_fill_({k[len("radar_vfe."):]: v for k, v in st.items() if k.startswith("radar_vfe.")}, seed=31)
+    seeded_fill_({k[len("radar_backbone_3d."):]: v for k, v in st.items() if k.startswith("radar_backbone_3d.")}, seed=32)
+    params = [k for k in st if st[k].is_floating_point() and "running" not in k]
+    if training:
+        for k in params:
+            st[k].requires_grad_(True)
+    ov = ovfe.dynamic_pillar_vfe(pts, st, "radar_vfe.", pc_range, voxel, gs, training=training)
+    ob = osp.pillar_res18_backbone(ov["pillar_features"], ov["pillar_coords"].numpy(), B, gs, st, "radar_backbone_3d.", training=training)
+    assert np.array_equal(bd["radar_pillar_coords"].cpu().numpy(), ov["pillar_coords"].numpy())
+    for k in ("x_conv1", "x_conv2", "x_conv3"):
+        f, idx, shape = ob[k]
+        assert np.array_equal(ms[k].indices.cpu().numpy(), idx), k
+        close(ms[k].features, f, what=k)
+    close(ms["x_conv4"], ob["x_conv4"], what="x_conv4"); close(ms["x_conv5"], ob["x_conv5"], what="x_conv5")
+    if training:
+        g4 = torch.from_numpy(np.random.default_rng(1).normal(size=tuple(ob["x_conv4"].shape)).astype(np.float32))
+        g5 = torch.from_numpy(np.random.default_rng(2).normal(size=tuple(ob["x_conv5"].shape)).astype(np.float32))
+        ((ms["x_conv4"] * g4.to(DEV)).sum() + (ms["x_conv5"] * g5.to(DEV)).sum()).backward()
+        ((ob["x_conv4"] * g4).sum() + (ob["x_conv5"] * g5).sum()).backward()
+        named = dict(("radar_vfe." + k, p) for k, p in vfe_m.named_parameters())
+        named.update(("radar_backbone_3d." + k, p) for k, p in bb.named_parameters())
+        worst = 0.0
+        for k in params:
+            a, b = named[k].grad.detach().cpu(), st[k].grad
+            denom = float(b.abs().max()) + 1e-6
+            worst = max(worst, float((a - b).abs().max()) / denom)
+            assert float((a - b).abs().max()) <= 2e-3 * denom + 1e-5, (k, float((a - b).abs().max()), denom)
+        print("worst relative grad error", worst)
+        # running statistics follow the reference's momentum update
+        for k, v in bb.state_dict().items():
+            if "running" in k:
+                close(v, st["radar_backbone_3d." + k], what=k)
