@@ -107,11 +107,14 @@ int rd_vfe_backward(const float *points, int n_points, int n_feat, const int32_t
  *    (base_bev_backbone.py:222-262, radar_distill_final.py:38-77, radar_center_head.py:40-45).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
-    int mode;            /* 0 TABLE (nbr[n_out][taps]), 1 DENSE conv, 2 DENSE_T (transposed conv / data-grad of strided conv) */
+    int mode;            /* 0 TABLE (nbr[n_out][taps]), 1 DENSE conv, 2 DENSE_T (transposed conv / data-grad of strided conv),
+                            3 DEFORM (DCNv2 sampling table from rd_dcn_prep) */
     const int32_t *nbr;  /* TABLE mode */
     int B, Hin, Win, Hout, Wout;   /* dense modes: input / output map sizes */
     int KH, KW, stride, pad;       /* dense modes */
     int flip;            /* TABLE mode: 1 = read table column (taps-1-t) for weight tap t (SubM data gradient) */
+    const int32_t *samp_idx;       /* DEFORM mode: [n_out][taps][4] input rows of the 4 bilinear corners, -1 = outside */
+    const float *samp_w;           /* DEFORM mode: [n_out][taps][4] mask * corner weight */
 } rd_conv_index;
 
 /* weight_k: kernel layout [Cout][taps][Cin] (Cin contiguous).  bias/scale/shift/residual may be NULL.
@@ -131,7 +134,8 @@ int rd_conv_wgrad(const float *in, int in_rows, int Cin, const float *grad_out, 
  *   kind 1: torch conv [Cout][Cin][kh][kw]  -> [Cout][taps][Cin]
  *   kind 2: data-gradient operand: from kernel layout [Cout][taps][Cin] -> [Cin][taps][Cout], flip reverses taps
  *   kind 3: torch ConvTranspose2d [Cin][Cout][kh][kw] -> kernel layout of the equivalent DENSE_T conv [Cout][taps][Cin]
- *   kind 4: inverse of kind 1 (kernel layout grad -> torch conv layout); kind 5: inverse of kind 3 */
+ *   kind 4: inverse of kind 1 (kernel layout grad -> torch conv layout); kind 5: inverse of kind 3
+ *   kind 6: kernel layout [Cout][taps][Cin] -> [taps][Cin][Cout] (DCN column-gradient operand) */
 int rd_weight_layout(const float *src, float *dst, int Cout, int Cin, int taps, int kind, int flip, void *stream);
 
 /* column sums: out[C] = sum_j x[j][:] (bias gradients); out zeroed inside. */
@@ -163,6 +167,68 @@ int rd_bn_bwd(const float *x, const float *y, const float *grad_y, int64_t rows,
  * ---------------------------------------------------------------------------------------------- */
 int rd_rows_to_dense(const float *feats, const int32_t *coords, int n, int C, int batch, int H, int W, float *dense, void *stream);
 int rd_dense_to_rows(const float *dense, const int32_t *coords, int n, int C, int batch, int H, int W, float *feats, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * F. DCNv2 (modulated deformable convolution), channels-last.  Replaces the `DCN` extension:
+ *    modulated_deform_conv_forward / _backward (pcdet/ops/basicblock/src/vision.cpp:9-10,
+ *    src/modulated_deform_conv.h:10-86, src/cuda/modulated_deform_conv_cuda.cu:19-280), deformable_groups = groups = 1.
+ *    offset rows: channel 2t = dh, 2t+1 = dw of tap t; mask rows: channel t; both given as (pointer, row stride) so
+ *    they can alias the fused 27-channel output of conv_offset_mask1; apply_sigmoid = 1 applies sigmoid to the mask.
+ *    Forward  = rd_dcn_prep + rd_conv_fwd(index mode 3)            (bias is ALWAYS added, as in the reference)
+ *    Backward = rd_conv_fwd (column gradient, weight kind 6) + rd_dcn_bwd_data + rd_conv_wgrad(index mode 3).
+ * ---------------------------------------------------------------------------------------------- */
+int rd_dcn_prep(const float *offset, int off_stride, const float *mask, int mask_stride, int apply_sigmoid, int B, int H, int W,
+                int Ho, int Wo, int KH, int KW, int stride, int pad, int dil, int32_t *samp_idx, float *samp_w, void *stream);
+/* x (B*H*W, C); colgrad (B*Ho*Wo, taps, C) = grad_out @ W per tap; outputs: grad_x (zeroed inside, atomics), grad of the
+ * offset / mask rows (written with the given row strides; mask gradient is w.r.t. the pre-sigmoid value when apply_sigmoid). */
+int rd_dcn_bwd_data(const float *x, int C, const float *colgrad, const float *offset, int off_stride, const float *mask, int mask_stride,
+                    int apply_sigmoid, int B, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad, int dil,
+                    float *grad_x, float *grad_offset, int goff_stride, float *grad_mask, int gmask_stride, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * G. Distillation losses over channels-last BEV maps.  Replaces Radar_Distill.low_loss (AFD) and high_loss (PFD),
+ *    pcdet/models/backbones_2d/radar_distill_final.py:82-141.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t rd_afd_ws_bytes(int64_t rows);
+/* AFD of two radar maps against one lidar map in one pass.  out[4] = (feature_a, mask_a, feature_b, mask_b);
+ * coef[6], rowinfo[2*rows*2] are saved for the backward. */
+int rd_afd_fwd(const float *lidar, const float *radar_a, const float *radar_b, int64_t rows, int C, int batch, float *out, float *coef,
+               float *rowinfo, float *ws, int64_t ws_bytes, void *stream);
+/* gscale[4] (device) = upstream gradients of out[4]. */
+int rd_afd_bwd(const float *lidar, const float *radar_a, const float *radar_b, int64_t rows, int C, const float *rowinfo, const float *coef,
+               const float *gscale, float *grad_a, float *grad_b, void *stream);
+/* PFD: gt_hm / hm_logits (rows, n_hm) concatenated heat-map channels; cls[rows] int8, counts[2] int32 saved for backward;
+ * out[1] = 0.5 * sum_cells w * (|softmax r1 - softmax l1|_1 + |softmax r2 - softmax l2|_1). */
+int rd_pfd_fwd(const float *r1, const float *l1, const float *r2, const float *l2, int64_t rows, int C, const float *gt_hm,
+               const float *hm_logits, int n_hm, int8_t *cls, int32_t *counts, float *out, float *ws, int64_t ws_bytes, void *stream);
+int rd_pfd_bwd(const float *r1, const float *l1, const float *r2, const float *l2, int64_t rows, int C, const int8_t *cls,
+               const int32_t *counts, const float *gscale, float *g1, float *g2, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * H. Rotated BEV overlap of aligned pairs.  Replaces iou3d_nms_cuda.boxes_aligned_overlap_bev_gpu(boxes_a (N,7),
+ *    boxes_b (N,7), ans (N,1)) (pcdet/ops/iou3d_nms/src/iou3d_nms_api.cpp:12, iou3d_nms.cpp:50-72).
+ * ---------------------------------------------------------------------------------------------- */
+int rd_boxes_aligned_overlap_bev(int n, const float *boxes_a, const float *boxes_b, float *ans_overlap, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * I. Optimizer: clip_grad_norm_ + OptimWrapper.step (decoupled decay + Adam) over all trainable tensors in two
+ *    launches (tools/train_utils/train_utils.py:60-64, optimization/fastai_optim.py:135-152).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    float *param;
+    const float *grad;
+    float *exp_avg;
+    float *exp_avg_sq;
+    int64_t numel;
+} rd_opt_tensor;
+int rd_opt_chunk_elems(void);   /* elements per chunk of the chunk table */
+/* tensors_dev: device array of rd_opt_tensor; chunks_dev: device array of (tensor id, element offset) int32 pairs.
+ * out2[0] = total 2-norm, out2[1] = clip coefficient min(1, max_norm / (norm + 1e-6)). */
+int rd_grad_norm(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, float max_norm, float *out2, float *ws,
+                 int64_t ws_bytes, void *stream);
+/* step = 1-based update count (bias correction).  clip_dev may be NULL (no clipping) or out2 of rd_grad_norm. */
+int rd_adam_step(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int step, const float *clip_dev, void *stream);
 
 #ifdef __cplusplus
 }

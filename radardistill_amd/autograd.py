@@ -78,7 +78,7 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, spec, Cout, stats):
         Cin = x.shape[1]
-        wk = kernel_weight(weight, Cout, Cin, spec.taps, spec.param_kind if spec.param_kind != 0 else 0)
+        wk = kernel_weight(weight, Cout, Cin, spec.taps, spec.param_kind)
         out = K.conv_fwd(x, wk, spec.taps, bias, spec.out_rows, Cout, spec.fwd_ix, stats=stats, nbr_keepalive=spec.fwd_nbr)
         ctx.spec, ctx.Cout, ctx.Cin = spec, Cout, Cin
         ctx.has_bias = bias is not None
@@ -92,9 +92,14 @@ class _ConvFn(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            wk = kernel_weight(weight, Cout, Cin, spec.taps, spec.param_kind if spec.param_kind != 0 else 0)
-            wd = K.weight_layout(wk, Cout, Cin, spec.taps, 2, False)          # [Cin][taps][Cout]
-            gx = K.conv_fwd(grad_out, wd, spec.taps, None, spec.in_rows, Cin, spec.bwd_ix, nbr_keepalive=spec.bwd_nbr)
+            wk = kernel_weight(weight, Cout, Cin, spec.taps, spec.param_kind)
+            go, Cp = grad_out, Cout
+            if Cout % 32 != 0:      # narrow heads (1..3, 27 channels): zero-pad the contraction dim to the kernel's K step
+                Cp = (Cout + 31) // 32 * 32
+                go = torch.nn.functional.pad(grad_out, (0, Cp - Cout))
+                wk = torch.nn.functional.pad(wk.reshape(Cout, -1), (0, 0, 0, Cp - Cout))
+            wd = K.weight_layout(wk.contiguous(), Cp, Cin, spec.taps, 2, False)          # [Cin][taps][Cout]
+            gx = K.conv_fwd(go, wd, spec.taps, None, spec.in_rows, Cin, spec.bwd_ix, nbr_keepalive=spec.bwd_nbr)
         if ctx.needs_input_grad[1]:
             gwk = K.conv_wgrad(x, grad_out, spec.taps, spec.fwd_ix)             # kernel layout
             if spec.param_kind == 0:
@@ -114,7 +119,7 @@ def conv(x, weight, bias, spec, Cout, stats=None):
 
 def conv_inference(x, weight, bias, spec, Cout, scale=None, shift=None, residual=None, relu=False):
     """Frozen path (teacher): conv + folded eval-mode BatchNorm + residual + ReLU in ONE kernel, no graph."""
-    wk = kernel_weight(weight, Cout, x.shape[1], spec.taps, spec.param_kind if spec.param_kind != 0 else 0)
+    wk = kernel_weight(weight, Cout, x.shape[1], spec.taps, spec.param_kind)
     return K.conv_fwd(x, wk, spec.taps, bias, spec.out_rows, Cout, spec.fwd_ix, scale=scale, shift=shift, residual=residual,
                       relu=relu, nbr_keepalive=spec.fwd_nbr)
 

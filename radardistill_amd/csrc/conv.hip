@@ -45,6 +45,10 @@ __device__ __forceinline__ int src_row(const ConvArgs &a, int j, int t) {
         int tt = ix.flip ? (a.taps - 1 - t) : t;
         return ix.nbr[(int64_t)j * a.taps + tt];
     }
+    if (ix.mode == 3) {  // deformable sampling: "has a source" == any of the 4 bilinear corners is inside the map
+        const int4 q = *reinterpret_cast<const int4 *>(ix.samp_idx + ((int64_t)j * a.taps + t) * 4);
+        return max(max(q.x, q.y), max(q.z, q.w));
+    }
     int ox = j % ix.Wout;
     int oy = (j / ix.Wout) % ix.Hout;
     int b = j / (ix.Wout * ix.Hout);
@@ -63,7 +67,7 @@ __device__ __forceinline__ int src_row(const ConvArgs &a, int j, int t) {
     return (b * ix.Hin + iy) * ix.Win + ixx;
 }
 
-template <int BN, int WAVES_M, int WAVES_N>
+template <int BN, int WAVES_M, int WAVES_N, bool DEFORM>
 __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int MI = WM / 32, NI = WN / 32;
@@ -107,6 +111,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
 
     f32x4 ra[4], rb[BP];
     int rows[4];
+    int4 sidx[DEFORM ? 4 : 1];
+    f32x4 sw[DEFORM ? 4 : 1];
     int cur_tap = -1, tap_iter_mask = tapmask;
 
     auto load_tile = [&](int s) {
@@ -114,13 +120,36 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
         if (s % kchunks == 0) {  // next active tap
             cur_tap = __ffs(tap_iter_mask) - 1;
             tap_iter_mask &= tap_iter_mask - 1;
+            if constexpr (DEFORM) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) rows[p] = src_row(a, m0 + ld_r + 32 * p, cur_tap);
+                for (int p = 0; p < 4; ++p) {
+                    const int j = m0 + ld_r + 32 * p;
+                    if (j < a.out_rows) {
+                        const int64_t o = ((int64_t)j * a.taps + cur_tap) * 4;
+                        sidx[p] = *reinterpret_cast<const int4 *>(a.ix.samp_idx + o);
+                        sw[p] = *reinterpret_cast<const f32x4 *>(a.ix.samp_w + o);
+                    } else {
+                        sidx[p] = make_int4(-1, -1, -1, -1);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) rows[p] = src_row(a, m0 + ld_r + 32 * p, cur_tap);
+            }
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (rows[p] >= 0) v = *reinterpret_cast<const f32x4 *>(a.in + (int64_t)rows[p] * a.Cin + kc + ld_c);
+            if constexpr (DEFORM) {
+                // A element = mask * bilinear(x): up to four weighted rows (weights already hold mask * corner weight)
+                const float *base = a.in + kc + ld_c;
+                if (sidx[p].x >= 0) v += sw[p][0] * *reinterpret_cast<const f32x4 *>(base + (int64_t)sidx[p].x * a.Cin);
+                if (sidx[p].y >= 0) v += sw[p][1] * *reinterpret_cast<const f32x4 *>(base + (int64_t)sidx[p].y * a.Cin);
+                if (sidx[p].z >= 0) v += sw[p][2] * *reinterpret_cast<const f32x4 *>(base + (int64_t)sidx[p].z * a.Cin);
+                if (sidx[p].w >= 0) v += sw[p][3] * *reinterpret_cast<const f32x4 *>(base + (int64_t)sidx[p].w * a.Cin);
+            } else {
+                if (rows[p] >= 0) v = *reinterpret_cast<const f32x4 *>(a.in + (int64_t)rows[p] * a.Cin + kc + ld_c);
+            }
             ra[p] = v;
         }
 #pragma unroll
@@ -220,6 +249,8 @@ static int validate_index(const rd_conv_index *ix, int taps, int in_rows, int ou
     RD_REQUIRE(taps >= 1 && taps <= MAX_TAPS, "%s: taps=%d outside 1..%d", who, taps, MAX_TAPS);
     if (ix->mode == 0) {
         RD_REQUIRE(ix->nbr != nullptr || out_rows == 0, "%s: TABLE mode needs nbr", who);
+    } else if (ix->mode == 3) {
+        RD_REQUIRE((ix->samp_idx != nullptr && ix->samp_w != nullptr) || out_rows == 0, "%s: DEFORM mode needs samp_idx / samp_w", who);
     } else {
         RD_REQUIRE(ix->mode == 1 || ix->mode == 2, "%s: bad index mode %d", who, ix->mode);
         RD_REQUIRE(ix->KH * ix->KW == taps, "%s: KH*KW=%d != taps=%d", who, ix->KH * ix->KW, taps);
@@ -243,15 +274,18 @@ extern "C" int rd_conv_fwd(const float *in, int in_rows, int Cin, const float *w
     ConvArgs a{in, in_rows, Cin, weight_k, taps, bias, out, out_rows, Cout, *idx, scale, shift, residual, relu, stats};
     hipStream_t st = S(stream);
     dim3 block(256);
-    if (Cout > 64) {
+    if (idx->mode == 3) {
         dim3 grid((unsigned)cdiv(out_rows, BM), (unsigned)cdiv(Cout, 128));
-        k_conv_igemm<128, 2, 2><<<grid, block, 0, st>>>(a);
+        k_conv_igemm<128, 2, 2, true><<<grid, block, 0, st>>>(a);
+    } else if (Cout > 64) {
+        dim3 grid((unsigned)cdiv(out_rows, BM), (unsigned)cdiv(Cout, 128));
+        k_conv_igemm<128, 2, 2, false><<<grid, block, 0, st>>>(a);
     } else if (Cout > 32) {
         dim3 grid((unsigned)cdiv(out_rows, BM), 1);
-        k_conv_igemm<64, 2, 2><<<grid, block, 0, st>>>(a);
+        k_conv_igemm<64, 2, 2, false><<<grid, block, 0, st>>>(a);
     } else {
         dim3 grid((unsigned)cdiv(out_rows, BM), 1);
-        k_conv_igemm<32, 4, 1><<<grid, block, 0, st>>>(a);
+        k_conv_igemm<32, 4, 1, false><<<grid, block, 0, st>>>(a);
     }
     return check_launch("rd_conv_fwd");
 }
@@ -282,6 +316,7 @@ __device__ __forceinline__ int src_row_w(const WgradArgs &a, int j, int t) {
     return src_row(c, j, t);
 }
 
+template <bool DEFORM>
 __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const WgradArgs a) {
     __shared__ __attribute__((aligned(16))) float G_l[2][WG_KB][WG_BM + 4];  // grad_out tile [k][cout]
     __shared__ __attribute__((aligned(16))) float X_l[2][WG_KB][WG_BN + 4];  // gathered input tile [k][cin]
@@ -317,10 +352,28 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const WgradArgs a) {
         for (int p = 0; p < 2; ++p) {
             int j = r0 + x_r + 16 * p;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            int src = (j < r_end) ? src_row_w(a, j, t) : -1;
-            if (src >= 0) {
-                any_next = 1;
-                if (ci0 + x_c < a.Cin) v = *reinterpret_cast<const f32x4 *>(a.in + (int64_t)src * a.Cin + ci0 + x_c);
+            if constexpr (DEFORM) {
+                if (j < r_end) {
+                    const int64_t o = ((int64_t)j * a.taps + t) * 4;
+                    const int4 q = *reinterpret_cast<const int4 *>(a.ix.samp_idx + o);
+                    if (max(max(q.x, q.y), max(q.z, q.w)) >= 0) {
+                        any_next = 1;
+                        if (ci0 + x_c < a.Cin) {
+                            const f32x4 w = *reinterpret_cast<const f32x4 *>(a.ix.samp_w + o);
+                            const float *base = a.in + ci0 + x_c;
+                            if (q.x >= 0) v += w[0] * *reinterpret_cast<const f32x4 *>(base + (int64_t)q.x * a.Cin);
+                            if (q.y >= 0) v += w[1] * *reinterpret_cast<const f32x4 *>(base + (int64_t)q.y * a.Cin);
+                            if (q.z >= 0) v += w[2] * *reinterpret_cast<const f32x4 *>(base + (int64_t)q.z * a.Cin);
+                            if (q.w >= 0) v += w[3] * *reinterpret_cast<const f32x4 *>(base + (int64_t)q.w * a.Cin);
+                        }
+                    }
+                }
+            } else {
+                int src = (j < r_end) ? src_row_w(a, j, t) : -1;
+                if (src >= 0) {
+                    any_next = 1;
+                    if (ci0 + x_c < a.Cin) v = *reinterpret_cast<const f32x4 *>(a.in + (int64_t)src * a.Cin + ci0 + x_c);
+                }
             }
             rx[p] = v;
         }
@@ -406,7 +459,8 @@ extern "C" int rd_conv_wgrad(const float *in, int in_rows, int Cin, const float 
     chunks = cdiv(out_rows, rows_per_block);
     WgradArgs a{in, in_rows, Cin, grad_out, out_rows, Cout, taps, *idx, grad_wk, rows_per_block};
     dim3 grid((unsigned)chunks, (unsigned)tiles);
-    k_conv_wgrad<<<grid, 256, 0, S(stream)>>>(a);
+    if (idx->mode == 3) k_conv_wgrad<true><<<grid, 256, 0, S(stream)>>>(a);
+    else k_conv_wgrad<false><<<grid, 256, 0, S(stream)>>>(a);
     return check_launch("rd_conv_wgrad");
 }
 
@@ -436,6 +490,9 @@ __global__ void k_weight_layout(const float *src, float *dst, int Cout, int Cin,
         int t = (int)(i % taps), c = (int)((i / taps) % Cin), n = (int)(i / ((int64_t)Cin * taps));
         int ts = flip ? taps - 1 - t : t;
         dst[i] = src[((int64_t)n * taps + ts) * Cin + c];
+    } else if (kind == 6) {  // kernel layout [Cout][taps][Cin] -> [taps][Cin][Cout]  (DCN column-gradient operand)
+        int n = (int)(i % Cout), c = (int)((i / Cout) % Cin), t = (int)(i / ((int64_t)Cout * Cin));
+        dst[i] = src[((int64_t)n * taps + t) * Cin + c];
     } else if (kind == 5) {  // [Cout][taps][Cin] -> torch ConvTranspose2d [Cin][Cout][taps]
         int t = (int)(i % taps), n = (int)((i / taps) % Cout), c = (int)(i / ((int64_t)Cout * taps));
         int ts = flip ? taps - 1 - t : t;
@@ -444,7 +501,7 @@ __global__ void k_weight_layout(const float *src, float *dst, int Cout, int Cin,
 }
 
 extern "C" int rd_weight_layout(const float *src, float *dst, int Cout, int Cin, int taps, int kind, int flip, void *stream) {
-    RD_REQUIRE(kind >= 0 && kind <= 5, "rd_weight_layout: bad kind %d", kind);
+    RD_REQUIRE(kind >= 0 && kind <= 6, "rd_weight_layout: bad kind %d", kind);
     int64_t total = (int64_t)Cout * Cin * taps;
     if (total <= 0) return RD_OK;
     k_weight_layout<<<cdiv(total, 256), 256, 0, S(stream)>>>(src, dst, Cout, Cin, taps, kind, flip);

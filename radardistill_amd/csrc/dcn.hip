@@ -1,0 +1,164 @@
+// DCNv2 (modulated deformable convolution) for channels-last maps.  Replaces the reference's in-tree CUDA op
+//   pcdet/ops/basicblock/src/cuda/modulated_deform_im2col_cuda.cuh:127-194 (im2col), :196-254 (col2im, atomics),
+//   :256-328 (col2im_coord) and modulated_deform_conv_cuda.cu:19-280 (im2col + cuBLAS GEMMs).
+// MI355X design: no im2col buffer in the forward.  rd_dcn_prep turns the offset/mask maps into a sampling table
+// (4 corner rows + 4 weights per (output pixel, tap), mask folded in); the implicit-GEMM kernel of conv.hip gathers
+// and blends the corner rows while it stages its A tile (index mode DEFORM), so the 2304 x BHW column matrix never
+// exists.  Backward: column gradient = one linear layer on the same kernel; rd_dcn_bwd_data turns it into the input
+// gradient (row-shaped fp32 atomics, 1 KiB contiguous per instruction) and the offset / mask gradients (wave reductions).
+#include "common.hpp"
+
+using namespace rd;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct DcnGeom {
+    int B, H, W, Ho, Wo, KH, KW, stride, pad, dil;
+};
+
+struct Sample {
+    int idx[4];
+    float w[4];      // bilinear corner weights (no mask)
+    float lh, lw;    // fractional parts
+    bool inside;
+};
+
+__device__ __forceinline__ Sample dcn_sample(const DcnGeom &g, int j, int t, float off_h, float off_w) {
+    Sample s;
+    const int wo = j % g.Wo, ho = (j / g.Wo) % g.Ho, b = j / (g.Wo * g.Ho);
+    const int ky = t / g.KW, kx = t % g.KW;
+    // modulated_deform_im2col_cuda.cuh:151-178: h_im = h_in + i*dilation + offset_h (float arithmetic)
+    const float h = (float)(ho * g.stride - g.pad + ky * g.dil) + off_h;
+    const float w = (float)(wo * g.stride - g.pad + kx * g.dil) + off_w;
+    s.inside = (h > -1.f) && (w > -1.f) && (h < (float)g.H) && (w < (float)g.W);
+    const float hl = floorf(h), wl = floorf(w);
+    const int h_low = (int)hl, w_low = (int)wl, h_high = h_low + 1, w_high = w_low + 1;
+    s.lh = h - hl;
+    s.lw = w - wl;
+    const float hh = 1.f - s.lh, hw = 1.f - s.lw;
+    s.w[0] = hh * hw; s.w[1] = hh * s.lw; s.w[2] = s.lh * hw; s.w[3] = s.lh * s.lw;
+    const bool ok0 = s.inside && h_low >= 0 && w_low >= 0;
+    const bool ok1 = s.inside && h_low >= 0 && w_high <= g.W - 1;
+    const bool ok2 = s.inside && h_high <= g.H - 1 && w_low >= 0;
+    const bool ok3 = s.inside && h_high <= g.H - 1 && w_high <= g.W - 1;
+    const int base = b * g.H;
+    s.idx[0] = ok0 ? (base + h_low) * g.W + w_low : -1;
+    s.idx[1] = ok1 ? (base + h_low) * g.W + w_high : -1;
+    s.idx[2] = ok2 ? (base + h_high) * g.W + w_low : -1;
+    s.idx[3] = ok3 ? (base + h_high) * g.W + w_high : -1;
+    return s;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+__global__ void k_dcn_prep(const float *__restrict__ offset, int off_stride, const float *__restrict__ mask, int mask_stride, int sig,
+                           DcnGeom g, int n_rows, int taps, int32_t *samp_idx, float *samp_w) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * taps) return;
+    const int j = i / taps, t = i % taps;
+    const float oh = offset[(int64_t)j * off_stride + 2 * t], ow = offset[(int64_t)j * off_stride + 2 * t + 1];
+    float m = mask[(int64_t)j * mask_stride + t];
+    if (sig) m = sigmoidf_(m);
+    Sample s = dcn_sample(g, j, t, oh, ow);
+    int4 q = make_int4(s.idx[0], s.idx[1], s.idx[2], s.idx[3]);
+    f32x4 w = {m * s.w[0], m * s.w[1], m * s.w[2], m * s.w[3]};
+    *reinterpret_cast<int4 *>(samp_idx + (int64_t)i * 4) = q;
+    *reinterpret_cast<f32x4 *>(samp_w + (int64_t)i * 4) = w;
+}
+
+static int check_geom(const DcnGeom &g, const char *who) {
+    RD_REQUIRE(g.B > 0 && g.H > 0 && g.W > 0 && g.KH > 0 && g.KW > 0 && g.KH * g.KW <= 16 && g.stride > 0 && g.dil > 0 && g.pad >= 0,
+               "%s: bad geometry", who);
+    int Ho = (g.H + 2 * g.pad - (g.dil * (g.KH - 1) + 1)) / g.stride + 1;
+    int Wo = (g.W + 2 * g.pad - (g.dil * (g.KW - 1) + 1)) / g.stride + 1;
+    RD_REQUIRE(Ho == g.Ho && Wo == g.Wo, "%s: output size (%d,%d) does not match geometry (%d,%d)", who, g.Ho, g.Wo, Ho, Wo);
+    return RD_OK;
+}
+
+extern "C" int rd_dcn_prep(const float *offset, int off_stride, const float *mask, int mask_stride, int apply_sigmoid, int B, int H, int W,
+                           int Ho, int Wo, int KH, int KW, int stride, int pad, int dil, int32_t *samp_idx, float *samp_w, void *stream) {
+    DcnGeom g{B, H, W, Ho, Wo, KH, KW, stride, pad, dil};
+    int rc = check_geom(g, "rd_dcn_prep");
+    if (rc) return rc;
+    const int taps = KH * KW;
+    RD_REQUIRE(off_stride >= 2 * taps && mask_stride >= taps, "rd_dcn_prep: row strides too small");
+    const int n_rows = B * Ho * Wo;
+    k_dcn_prep<<<cdiv((int64_t)n_rows * taps, 256), 256, 0, S(stream)>>>(offset, off_stride, mask, mask_stride, apply_sigmoid, g, n_rows, taps,
+                                                                         samp_idx, samp_w);
+    return check_launch("rd_dcn_prep");
+}
+
+// One wave per (output pixel j, tap t); lanes sweep the C channels 4 at a time (C % 256 == 0 -> C/256 float4 per lane).
+__global__ __launch_bounds__(256) void k_dcn_bwd_data(const float *__restrict__ x, int C, const float *__restrict__ colgrad,
+                                                      const float *__restrict__ offset, int off_stride, const float *__restrict__ mask,
+                                                      int mask_stride, int sig, DcnGeom g, int n_rows, int taps, float *grad_x,
+                                                      float *grad_offset, int goff_stride, float *grad_mask, int gmask_stride) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pair = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (pair >= (int64_t)n_rows * taps) return;
+    const int j = (int)(pair / taps), t = (int)(pair % taps);
+    const float oh = offset[(int64_t)j * off_stride + 2 * t], ow = offset[(int64_t)j * off_stride + 2 * t + 1];
+    float mraw = mask[(int64_t)j * mask_stride + t];
+    const float m = sig ? sigmoidf_(mraw) : mraw;
+    const Sample s = dcn_sample(g, j, t, oh, ow);
+    float dmask = 0.f, dh = 0.f, dw = 0.f;
+    if (s.inside) {
+        const float hh = 1.f - s.lh, hw = 1.f - s.lw;
+        const float *gc = colgrad + ((int64_t)j * taps + t) * C;
+        for (int c = lane * 4; c < C; c += 256) {
+            const f32x4 gv = *reinterpret_cast<const f32x4 *>(gc + c);
+            f32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (s.idx[k] >= 0) v[k] = *reinterpret_cast<const f32x4 *>(x + (int64_t)s.idx[k] * C + c);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float val = s.w[0] * v[0][e] + s.w[1] * v[1][e] + s.w[2] * v[2][e] + s.w[3] * v[3][e];
+                dmask += gv[e] * val;
+                // mdmcn_get_coordinate_weight (modulated_deform_im2col_cuda.cuh:84-125)
+                dh += gv[e] * (-hw * v[0][e] - s.lw * v[1][e] + hw * v[2][e] + s.lw * v[3][e]);
+                dw += gv[e] * (-hh * v[0][e] + hh * v[1][e] - s.lh * v[2][e] + s.lh * v[3][e]);
+            }
+            // input gradient: grad_x[corner] += mask * corner weight * column gradient  (col2im, :196-254)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (s.idx[k] >= 0) {
+                    float *dst = grad_x + (int64_t)s.idx[k] * C + c;
+                    const float wk = m * s.w[k];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd(dst + e, wk * gv[e]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        dmask += __shfl_xor(dmask, d, 64);
+        dh += __shfl_xor(dh, d, 64);
+        dw += __shfl_xor(dw, d, 64);
+    }
+    if (lane == 0) {
+        grad_offset[(int64_t)j * goff_stride + 2 * t] = dh * m;
+        grad_offset[(int64_t)j * goff_stride + 2 * t + 1] = dw * m;
+        grad_mask[(int64_t)j * gmask_stride + t] = sig ? dmask * m * (1.f - m) : dmask;
+    }
+}
+
+extern "C" int rd_dcn_bwd_data(const float *x, int C, const float *colgrad, const float *offset, int off_stride, const float *mask,
+                               int mask_stride, int apply_sigmoid, int B, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad,
+                               int dil, float *grad_x, float *grad_offset, int goff_stride, float *grad_mask, int gmask_stride, void *stream) {
+    DcnGeom g{B, H, W, Ho, Wo, KH, KW, stride, pad, dil};
+    int rc = check_geom(g, "rd_dcn_bwd_data");
+    if (rc) return rc;
+    RD_REQUIRE(C > 0 && C % 4 == 0, "rd_dcn_bwd_data: C=%d must be a multiple of 4", C);
+    const int taps = KH * KW;
+    hipStream_t st = S(stream);
+    RD_HIP(hipMemsetAsync(grad_x, 0, (size_t)B * H * W * C * 4, st));
+    const int64_t pairs = (int64_t)B * Ho * Wo * taps;
+    if (pairs == 0) return RD_OK;
+    k_dcn_bwd_data<<<cdiv(pairs, 4), 256, 0, st>>>(x, C, colgrad, offset, off_stride, mask, mask_stride, apply_sigmoid, g, B * Ho * Wo, taps,
+                                                   grad_x, grad_offset, goff_stride, grad_mask, gmask_stride);
+    return check_launch("rd_dcn_bwd_data");
+}

@@ -1,0 +1,98 @@
+// Optimizer step of the reference training loop as two multi-tensor kernels (no per-tensor launches, no host sync):
+//   1. global gradient 2-norm (clip_grad_norm_(10), tools/train_utils/train_utils.py:62)
+//   2. decoupled weight decay p *= 1 - wd*lr, then Adam (tools/train_utils/optimization/fastai_optim.py:135-152 +
+//      torch.optim.Adam, betas = (momentum of the one-cycle schedule, 0.99), eps 1e-8), with the clip coefficient
+//      read from device memory.
+// HBM-bound: reads p, g, m, v and writes p, m, v once (28 B / parameter).  Tensors are described by a device table so
+// the ~500 parameter tensors of the student are one launch; each block owns one 4096-element chunk of one tensor.
+#include "common.hpp"
+
+using namespace rd;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int OPT_CHUNK = 4096;
+
+// chunk table entry: tensor id + element offset of the chunk
+__global__ __launch_bounds__(256) void k_gradnorm_partial(const rd_opt_tensor *__restrict__ tensors, const int2 *__restrict__ chunks, int n_chunks,
+                                                          float *partial) {
+    __shared__ float red[4];
+    const int2 ch = chunks[blockIdx.x];
+    const rd_opt_tensor t = tensors[ch.x];
+    const float *g = t.grad + ch.y;
+    const int64_t n = min((int64_t)OPT_CHUNK, t.numel - ch.y);
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        float v = g[i];
+        s += v * v;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void k_gradnorm_final(const float *partial, int n, float max_norm, float *out /*[2]: total_norm, clip_coef*/) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if (threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float total = (float)sqrt(red[0]);
+        out[0] = total;
+        float coef = max_norm / (total + 1e-6f);
+        out[1] = coef < 1.f ? coef : 1.f;       // torch.clamp(max=1.0); NaN total -> NaN coef -> NaN update, as in torch
+        if (!(coef == coef)) out[1] = coef;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_adam(const rd_opt_tensor *__restrict__ tensors, const int2 *__restrict__ chunks, float lr, float beta1,
+                                              float beta2, float eps, float wd, float bc1, float bc2_sqrt, const float *__restrict__ clip) {
+    const int2 ch = chunks[blockIdx.x];
+    const rd_opt_tensor t = tensors[ch.x];
+    const int64_t n = min((int64_t)OPT_CHUNK, t.numel - ch.y);
+    float *p = t.param + ch.y;
+    const float *g = t.grad + ch.y;
+    float *m = t.exp_avg + ch.y, *v = t.exp_avg_sq + ch.y;
+    const float cc = clip ? clip[1] : 1.f;
+    const float decay = 1.f - wd * lr, step = lr / bc1;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const float gi = g[i] * cc;
+        float pi = p[i] * decay;
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi -= step * (mi / denom);
+        p[i] = pi;
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+extern "C" int rd_grad_norm(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, float max_norm, float *out2,
+                            float *ws, int64_t ws_bytes, void *stream) {
+    RD_REQUIRE(n_chunks >= 0 && ws_bytes >= (int64_t)n_chunks * 4, "rd_grad_norm: workspace too small");
+    hipStream_t st = S(stream);
+    if (n_chunks > 0)
+        k_gradnorm_partial<<<n_chunks, 256, 0, st>>>(tensors_dev, reinterpret_cast<const int2 *>(chunks_dev), n_chunks, ws);
+    k_gradnorm_final<<<1, 256, 0, st>>>(ws, n_chunks, max_norm, out2);
+    return check_launch("rd_grad_norm");
+}
+
+extern "C" int rd_adam_step(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, int step, const float *clip_dev, void *stream) {
+    RD_REQUIRE(step >= 1, "rd_adam_step: step must be >= 1");
+    if (n_chunks <= 0) return RD_OK;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    k_adam<<<n_chunks, 256, 0, S(stream)>>>(tensors_dev, reinterpret_cast<const int2 *>(chunks_dev), lr, beta1, beta2, eps, weight_decay,
+                                            (float)bc1, (float)sqrt(bc2), clip_dev);
+    return check_launch("rd_adam_step");
+}
+
+extern "C" int rd_opt_chunk_elems(void) { return OPT_CHUNK; }

@@ -279,3 +279,99 @@ def dense_to_rows(dense, coords, batch, H, W):
     feats = torch.empty((n, C), dtype=f32, device=dense.device)
     check(native.lib().rd_dense_to_rows(_p(dense), _p(coords), n, C, batch, H, W, _p(feats), _stream()), "rd_dense_to_rows")
     return feats
+
+
+# ------------------------------------------------------------------------------------------ DCNv2
+def dcn_prep(offset_base, off_stride, mask_base, mask_stride, apply_sigmoid, B, H, W, Ho, Wo, k, stride, pad, dil=1):
+    """offset_base / mask_base: tensors whose data_ptr is the first offset / mask channel of row 0."""
+    taps = k * k
+    rows = B * Ho * Wo
+    dev = offset_base.device
+    samp_idx = torch.empty((rows, taps, 4), dtype=i32, device=dev)
+    samp_w = torch.empty((rows, taps, 4), dtype=f32, device=dev)
+    check(native.lib().rd_dcn_prep(_p(offset_base), off_stride, _p(mask_base), mask_stride, int(apply_sigmoid), B, H, W, Ho, Wo, k, k,
+                                   stride, pad, dil, _p(samp_idx), _p(samp_w), _stream()), "rd_dcn_prep")
+    return samp_idx, samp_w
+
+
+def conv_index_deform(samp_idx, samp_w):
+    ix = ConvIndex()
+    ix.mode = 3
+    ix.nbr = None
+    ix.samp_idx = samp_idx.data_ptr()
+    ix.samp_w = samp_w.data_ptr()
+    return ix
+
+
+def dcn_bwd_data(x_rows, colgrad, offset_base, off_stride, mask_base, mask_stride, apply_sigmoid, B, H, W, Ho, Wo, k, stride, pad,
+                 grad_offset_base, goff_stride, grad_mask_base, gmask_stride, dil=1):
+    _chk(x_rows, f32, "dcn x", 2); _chk(colgrad, f32, "dcn colgrad")
+    C = x_rows.shape[1]
+    if x_rows.shape[0] != B * H * W or colgrad.numel() != B * Ho * Wo * k * k * C:
+        raise RuntimeError("dcn_bwd_data: shape mismatch")
+    gx = torch.empty_like(x_rows)
+    check(native.lib().rd_dcn_bwd_data(_p(x_rows), C, _p(colgrad), _p(offset_base), off_stride, _p(mask_base), mask_stride,
+                                       int(apply_sigmoid), B, H, W, Ho, Wo, k, k, stride, pad, dil, _p(gx), _p(grad_offset_base),
+                                       goff_stride, _p(grad_mask_base), gmask_stride, _stream()), "rd_dcn_bwd_data")
+    return gx
+
+
+# ------------------------------------------------------------------------------------------ distillation losses
+def afd_fwd(lidar, radar_a, radar_b, batch):
+    for t in (lidar, radar_a, radar_b):
+        _chk(t, f32, "afd map", 2)
+    if not (lidar.shape == radar_a.shape == radar_b.shape):
+        raise RuntimeError("afd_fwd: map shapes differ")
+    rows, C = lidar.shape
+    dev = lidar.device
+    out = torch.empty(4, dtype=f32, device=dev)
+    coef = torch.empty(6, dtype=f32, device=dev)
+    rowinfo = torch.empty(2 * rows * 2, dtype=f32, device=dev)
+    nb = native.lib().rd_afd_ws_bytes(rows)
+    ws = torch.empty(nb // 4, dtype=f32, device=dev)
+    check(native.lib().rd_afd_fwd(_p(lidar), _p(radar_a), _p(radar_b), rows, C, batch, _p(out), _p(coef), _p(rowinfo), _p(ws), nb, _stream()),
+          "rd_afd_fwd")
+    return out, coef, rowinfo
+
+
+def afd_bwd(lidar, radar_a, radar_b, rowinfo, coef, gscale):
+    rows, C = lidar.shape
+    ga, gb = torch.empty_like(radar_a), torch.empty_like(radar_b)
+    check(native.lib().rd_afd_bwd(_p(lidar), _p(radar_a), _p(radar_b), rows, C, _p(rowinfo), _p(coef), _p(_chk(gscale, f32, "gscale")),
+                                  _p(ga), _p(gb), _stream()), "rd_afd_bwd")
+    return ga, gb
+
+
+def pfd_fwd(r1, l1, r2, l2, gt_hm, hm_logits):
+    for t in (r1, l1, r2, l2, gt_hm, hm_logits):
+        _chk(t, f32, "pfd map", 2)
+    rows, C = r1.shape
+    if not (l1.shape == r2.shape == l2.shape == r1.shape) or gt_hm.shape != hm_logits.shape or gt_hm.shape[0] != rows:
+        raise RuntimeError("pfd_fwd: shape mismatch")
+    dev = r1.device
+    cls = torch.empty(rows, dtype=torch.int8, device=dev)
+    counts = torch.empty(2, dtype=i32, device=dev)
+    out = torch.empty(1, dtype=f32, device=dev)
+    ws = torch.empty(1024, dtype=f32, device=dev)
+    check(native.lib().rd_pfd_fwd(_p(r1), _p(l1), _p(r2), _p(l2), rows, C, _p(gt_hm), _p(hm_logits), gt_hm.shape[1], _p(cls), _p(counts),
+                                  _p(out), _p(ws), 4096, _stream()), "rd_pfd_fwd")
+    return out, cls, counts
+
+
+def pfd_bwd(r1, l1, r2, l2, cls, counts, gscale):
+    rows, C = r1.shape
+    g1, g2 = torch.empty_like(r1), torch.empty_like(r2)
+    check(native.lib().rd_pfd_bwd(_p(r1), _p(l1), _p(r2), _p(l2), rows, C, _p(cls), _p(counts), _p(_chk(gscale, f32, "gscale")),
+                                  _p(g1), _p(g2), _stream()), "rd_pfd_bwd")
+    return g1, g2
+
+
+# ------------------------------------------------------------------------------------------ rotated overlap
+def boxes_aligned_overlap_bev(boxes_a, boxes_b):
+    _chk(boxes_a, f32, "boxes_a", 2); _chk(boxes_b, f32, "boxes_b", 2)
+    if boxes_a.shape != boxes_b.shape or boxes_a.shape[1] != 7:
+        raise RuntimeError("boxes_aligned_overlap_bev: expected two (N,7) tensors")
+    n = boxes_a.shape[0]
+    out = torch.zeros((n, 1), dtype=f32, device=boxes_a.device)
+    check(native.lib().rd_boxes_aligned_overlap_bev(n, _p(boxes_a), _p(boxes_b), _p(out), _stream()), "rd_boxes_aligned_overlap_bev")
+    return out

@@ -20,7 +20,8 @@ c_int, c_i64, c_f32, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes
 class ConvIndex(ctypes.Structure):
     """rd_conv_index of include/rdamd.h."""
     _fields_ = [("mode", c_int), ("nbr", c_vp), ("B", c_int), ("Hin", c_int), ("Win", c_int), ("Hout", c_int),
-                ("Wout", c_int), ("KH", c_int), ("KW", c_int), ("stride", c_int), ("pad", c_int), ("flip", c_int)]
+                ("Wout", c_int), ("KH", c_int), ("KW", c_int), ("stride", c_int), ("pad", c_int), ("flip", c_int),
+                ("samp_idx", c_vp), ("samp_w", c_vp)]
 
 
 # name -> (restype, argtypes).  Must list EVERY symbol declared in include/rdamd.h (tests check this).
@@ -52,6 +53,17 @@ SIGNATURES = {
     "rd_bn_bwd": (c_int, [_P, _P, _P, c_i64, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, c_i64, _P]),
     "rd_rows_to_dense": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "rd_dense_to_rows": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "rd_dcn_prep": (c_int, [_P, c_int, _P, c_int, c_int] + [c_int] * 10 + [_P, _P, _P]),
+    "rd_dcn_bwd_data": (c_int, [_P, c_int, _P, _P, c_int, _P, c_int, c_int] + [c_int] * 10 + [_P, _P, c_int, _P, c_int, _P]),
+    "rd_afd_ws_bytes": (c_i64, [c_i64]),
+    "rd_afd_fwd": (c_int, [_P, _P, _P, c_i64, c_int, c_int, _P, _P, _P, _P, c_i64, _P]),
+    "rd_afd_bwd": (c_int, [_P, _P, _P, c_i64, c_int, _P, _P, _P, _P, _P, _P]),
+    "rd_pfd_fwd": (c_int, [_P, _P, _P, _P, c_i64, c_int, _P, _P, c_int, _P, _P, _P, _P, c_i64, _P]),
+    "rd_pfd_bwd": (c_int, [_P, _P, _P, _P, c_i64, c_int, _P, _P, _P, _P, _P, _P]),
+    "rd_boxes_aligned_overlap_bev": (c_int, [c_int, _P, _P, _P, _P]),
+    "rd_opt_chunk_elems": (c_int, []),
+    "rd_grad_norm": (c_int, [_P, _P, c_int, c_f32, _P, _P, c_i64, _P]),
+    "rd_adam_step": (c_int, [_P, _P, c_int, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, _P, _P]),
 }
 
 

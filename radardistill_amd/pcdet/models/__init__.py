@@ -1,0 +1,46 @@
+"""build_network / load_data_to_gpu / model_fn_decorator: the reference's training entry points
+(pcdet/models/__init__.py:16-54)."""
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+from .detectors import build_detector
+
+
+def build_network(model_cfg, num_class, dataset):
+    return build_detector(model_cfg=model_cfg, num_class=num_class, dataset=dataset)
+
+
+def load_data_to_gpu(batch_dict):
+    """numpy -> float32 CUDA tensors (reference: pageable `.cuda()` per key).  Host arrays go through pinned staging and
+    non-blocking copies; `gt_boxes` additionally keeps a host copy (`gt_boxes_host`) so the CPU-side target assignment
+    does not have to read it back."""
+    for key, val in list(batch_dict.items()):
+        if not isinstance(val, np.ndarray):
+            continue
+        if key in ['frame_id', 'metadata', 'calib', 'image_paths', 'ori_shape', 'img_process_infos']:
+            continue
+        if key == 'gt_boxes':
+            batch_dict['gt_boxes_host'] = val
+        if key in ['image_shape']:
+            batch_dict[key] = torch.from_numpy(val).int().cuda(non_blocking=True)
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(val, dtype=np.float32))
+            batch_dict[key] = t.pin_memory().cuda(non_blocking=True) if torch.cuda.is_available() else t
+
+
+def model_fn_decorator():
+    ModelReturn = namedtuple('ModelReturn', ['loss', 'tb_dict', 'disp_dict'])
+
+    def model_func(model, batch_dict):
+        load_data_to_gpu(batch_dict)
+        ret_dict, tb_dict, disp_dict = model(batch_dict)
+        loss = ret_dict['loss'].mean()
+        if hasattr(model, 'update_global_step'):
+            model.update_global_step()
+        else:
+            model.module.update_global_step()
+        return ModelReturn(loss, tb_dict, disp_dict)
+
+    return model_func

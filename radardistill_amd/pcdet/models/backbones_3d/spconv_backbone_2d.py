@@ -12,15 +12,14 @@ from functools import partial
 import torch
 import torch.nn as nn
 
-from .... import autograd as A
-from .... import kernels as K
-from ....sparse import SparseConvTensor
-from ...utils.spconv_utils import replace_feature, spconv
+from radardistill_amd import autograd as A
+from radardistill_amd import dense as D
+from radardistill_amd import kernels as K
+from radardistill_amd.sparse import SparseConvTensor
+from radardistill_amd.pcdet.utils.spconv_utils import replace_feature, spconv
 
 
-def _frozen(*mods):
-    """True when the fused inference path applies: eval-mode BN and no gradient wanted."""
-    return (not torch.is_grad_enabled()) or all((not m.training) and not any(p.requires_grad for p in m.parameters()) for m in mods)
+_frozen = D.frozen
 
 
 class _SparseConvBNReLU(spconv.SparseSequential):
@@ -62,27 +61,7 @@ class _DenseConvBNReLU(nn.Sequential):
 
 
 def dense_conv_bn_act(x, conv, bn, residual_rows=None, act=1, return_rows=False):
-    """(B,Cin,H,W) -> conv2d -> BatchNorm2d -> (+residual) -> act on the implicit-GEMM kernel.  `conv` is an nn.Conv2d used
-    as a parameter container; zero padding only."""
-    rows, B, H, W = A.nchw_to_rows(x)
-    kh, kw = conv.kernel_size
-    spec = A.dense_conv_spec(B, H, W, kh, kw, conv.stride[0], conv.padding[0])
-    Ho, Wo = spec.out_hw
-    Cout = conv.out_channels
-    if bn is None:
-        out = A.conv(rows, conv.weight, conv.bias, spec, Cout, None) if torch.is_grad_enabled() else \
-            A.conv_inference(rows, conv.weight, conv.bias, spec, Cout)
-    elif not bn.training and _frozen(conv, bn) and act in (0, 1):
-        scale, shift = A.bn_eval_scale_shift(bn)
-        out = A.conv_inference(rows, conv.weight, conv.bias, spec, Cout, scale, shift, residual_rows, act == 1)
-    elif bn.training:
-        stats = torch.zeros(2 * Cout, dtype=torch.float32, device=rows.device)
-        raw = A.conv(rows, conv.weight, conv.bias, spec, Cout, stats)
-        out = A.bn_act_train(raw, bn, residual_rows, act=act, stats=stats)
-    else:
-        raw = A.conv(rows, conv.weight, conv.bias, spec, Cout, None)
-        out = A.bn_act_eval(raw, bn, residual_rows, act=act)
-    return out if return_rows else A.rows_to_nchw(out, B, Ho, Wo)
+    return D.conv_bn_act(x, conv, bn, residual_rows, act, return_rows)
 
 
 def post_act_block_dense(in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, norm_fn=None):

@@ -9,8 +9,8 @@ Linear -> BatchNorm -> ReLU -> per-pillar max kernel (two passes in training, fo
 import torch
 import torch.nn as nn
 
-from .... import kernels as K
-from .... import sparse as SP
+from radardistill_amd import kernels as K
+from radardistill_amd import sparse as SP
 from .vfe_template import VFETemplate
 
 

@@ -1,0 +1,263 @@
+"""CenterHead (teacher) / Radar_CenterHead (student) on the MI355X kernels.
+
+Constructor signature, module tree (shared_conv, heads_list.H.{center,center_z,dim,rot,vel,iou,hm}), forward_ret_dict,
+batch_dict keys, target format and loss values follow the reference's
+pcdet/models/dense_heads/radar_center_head.py:28-440 and center_head.py:390-424.
+Convolutions run on the implicit-GEMM MFMA kernel; the loss has no host synchronisation (see utils/loss_utils.py).
+Only the training path of the distill config is implemented: `generate_predicted_boxes` (eval decode + NMS) is a
+"next" row of SURVEY section 8(f).
+"""
+import copy
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn.init import kaiming_normal_
+
+from radardistill_amd import autograd as A
+from radardistill_amd import dense as D
+from ...utils import loss_utils
+from ...utils.loss_utils import IouLoss, IouRegLoss
+from ..model_utils import centernet_utils
+
+
+class SeparateHead(nn.Module):
+    def __init__(self, input_channels, sep_head_dict, init_bias=-2.19, use_bias=False):
+        super().__init__()
+        self.sep_head_dict = sep_head_dict
+        for cur_name in self.sep_head_dict:
+            output_channels = self.sep_head_dict[cur_name]['out_channels']
+            num_conv = self.sep_head_dict[cur_name]['num_conv']
+            fc_list = []
+            for k in range(num_conv - 1):
+                fc_list.append(nn.Sequential(
+                    nn.Conv2d(input_channels, input_channels, kernel_size=3, stride=1, padding=1, bias=use_bias),
+                    nn.BatchNorm2d(input_channels), nn.ReLU()))
+            fc_list.append(nn.Conv2d(input_channels, output_channels, kernel_size=3, stride=1, padding=1, bias=True))
+            fc = nn.Sequential(*fc_list)
+            if 'hm' in cur_name:
+                fc[-1].bias.data.fill_(init_bias)
+            else:
+                for m in fc.modules():
+                    if isinstance(m, nn.Conv2d):
+                        kaiming_normal_(m.weight.data)
+                        if hasattr(m, "bias") and m.bias is not None:
+                            nn.init.constant_(m.bias, 0)
+            self.__setattr__(cur_name, fc)
+
+    def forward(self, x):
+        """x: (rows, B, H, W) channels-last rows of the shared feature."""
+        ret_dict = {}
+        for cur_name in self.sep_head_dict:
+            fc = self.__getattr__(cur_name)
+            state = x
+            for m in fc:
+                if isinstance(m, nn.Sequential):
+                    out, B, H, W = D.conv_bn_act(None, m[0], m[1], None, act=1, return_rows=True, in_rows=state)
+                else:
+                    out, B, H, W = D.conv_bn_act(None, m, None, None, act=0, return_rows=True, in_rows=state)
+                state = (out, B, H, W)
+            ret_dict[cur_name] = A.rows_to_nchw(*state)
+        return ret_dict
+
+
+class Radar_CenterHead(nn.Module):
+    FEATURE_KEY = 'radar_spatial_features_2d'
+    IS_TEACHER = False
+
+    def __init__(self, model_cfg, input_channels, num_class, class_names, grid_size, point_cloud_range, voxel_size,
+                 predict_boxes_when_training=True, bn_folding=False):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.num_class = num_class
+        self.grid_size = grid_size
+        self.point_cloud_range = point_cloud_range
+        self.voxel_size = voxel_size
+        self.feature_map_stride = self.model_cfg.TARGET_ASSIGNER_CONFIG.get('FEATURE_MAP_STRIDE', None)
+        self.class_names = class_names
+        self.class_names_each_head = []
+        self.class_id_mapping_each_head = []
+        self.waymo = model_cfg.get("waymo", False)
+        for cur_class_names in self.model_cfg.CLASS_NAMES_EACH_HEAD:
+            self.class_names_each_head.append([x for x in cur_class_names if x in class_names])
+            self.class_id_mapping_each_head.append(torch.from_numpy(np.array(
+                [self.class_names.index(x) for x in cur_class_names if x in class_names])))
+        total_classes = sum([len(x) for x in self.class_names_each_head])
+        assert total_classes == len(self.class_names), f'class_names_each_head={self.class_names_each_head}'
+        self.shared_conv = nn.Sequential(
+            nn.Conv2d(input_channels, self.model_cfg.SHARED_CONV_CHANNEL, 3, stride=1, padding=1,
+                      bias=self.model_cfg.get('USE_BIAS_BEFORE_NORM', False)),
+            nn.BatchNorm2d(self.model_cfg.SHARED_CONV_CHANNEL), nn.ReLU())
+        self.heads_list = nn.ModuleList()
+        self.separate_head_cfg = self.model_cfg.SEPARATE_HEAD_CFG
+        for idx, cur_class_names in enumerate(self.class_names_each_head):
+            cur_head_dict = copy.deepcopy(dict(self.separate_head_cfg.HEAD_DICT))
+            cur_head_dict['hm'] = dict(out_channels=len(cur_class_names), num_conv=self.model_cfg.NUM_HM_CONV)
+            self.heads_list.append(SeparateHead(input_channels=self.model_cfg.SHARED_CONV_CHANNEL, sep_head_dict=cur_head_dict,
+                                                init_bias=-2.19, use_bias=self.model_cfg.get('USE_BIAS_BEFORE_NORM', False)))
+        self.predict_boxes_when_training = predict_boxes_when_training
+        self.forward_ret_dict = {}
+        self.with_iou = 'iou' in self.model_cfg.SEPARATE_HEAD_CFG.HEAD_DICT
+        self.with_iou_reg = self.model_cfg.get("IOU_REG", False)
+        if self.with_iou:
+            self.crit_iou = IouLoss()
+        self.crit_iou_reg = None
+        if self.with_iou_reg:
+            self.crit_iou_reg = IouRegLoss(self.with_iou_reg)
+        self.build_losses()
+        self.bn_folding = bn_folding
+
+    def build_losses(self):
+        self.add_module('hm_loss_func', loss_utils.FocalLossCenterNet())
+        self.add_module('reg_loss_func', loss_utils.RegLossCenterNet())
+
+    # ------------------------------------------------------------------ target assignment (host, exact reference arithmetic)
+    def assign_target_of_single_head(self, num_classes, gt_boxes, feature_map_size, feature_map_stride, num_max_objs=500,
+                                     gaussian_overlap=0.1, min_radius=2):
+        """gt_boxes: CPU (n, 10) with the last column the 1-based class id inside this head; feature_map_size = [x, y]."""
+        fx, fy = int(feature_map_size[0]), int(feature_map_size[1])
+        heatmap = gt_boxes.new_zeros(num_classes, fy, fx)
+        ret_boxes = gt_boxes.new_zeros((num_max_objs, gt_boxes.shape[-1] - 1 + 1))
+        gt_box = gt_boxes.new_zeros((num_max_objs, gt_boxes.shape[-1] - (1 if self.waymo else 3)))
+        inds = gt_boxes.new_zeros(num_max_objs).long()
+        mask = gt_boxes.new_zeros(num_max_objs).long()
+        n = min(num_max_objs, gt_boxes.shape[0])
+        if n == 0:
+            return heatmap, ret_boxes, inds, mask, gt_box
+        x, y, z = gt_boxes[:, 0], gt_boxes[:, 1], gt_boxes[:, 2]
+        coord_x = (x - self.point_cloud_range[0]) / self.voxel_size[0] / feature_map_stride
+        coord_y = (y - self.point_cloud_range[1]) / self.voxel_size[1] / feature_map_stride
+        coord_x = torch.clamp(coord_x, min=0, max=fx - 0.5)
+        coord_y = torch.clamp(coord_y, min=0, max=fy - 0.5)
+        center = torch.cat((coord_x[:, None], coord_y[:, None]), dim=-1)
+        center_int = center.int()
+        dx = gt_boxes[:, 3] / self.voxel_size[0] / feature_map_stride
+        dy = gt_boxes[:, 4] / self.voxel_size[1] / feature_map_stride
+        radius = torch.clamp_min(centernet_utils.gaussian_radius(dx, dy, min_overlap=gaussian_overlap).int(), min=min_radius)
+        ok = (dx[:n] > 0) & (dy[:n] > 0) & (center_int[:n, 0] >= 0) & (center_int[:n, 0] <= fx) & \
+            (center_int[:n, 1] >= 0) & (center_int[:n, 1] <= fy)
+        cls = (gt_boxes[:n, -1] - 1).long()
+        rad = radius[:n].tolist()
+        ci = center_int[:n].tolist()
+        for k in torch.nonzero(ok).flatten().tolist():
+            centernet_utils.draw_gaussian_to_heatmap(heatmap[cls[k]], ci[k], rad[k])
+        # vectorised slot fill (rows that fail `ok` stay zero, like the reference's `continue`)
+        okf = ok
+        inds[:n] = torch.where(okf, center_int[:n, 1].long() * fx + center_int[:n, 0].long(), inds[:n])
+        mask[:n] = okf.long()
+        rb = torch.zeros((n, ret_boxes.shape[1]), dtype=gt_boxes.dtype)
+        rb[:, 0:2] = center[:n] - center_int[:n].float()
+        rb[:, 2] = z[:n]
+        rb[:, 3:6] = gt_boxes[:n, 3:6].log()
+        rb[:, 6] = torch.cos(gt_boxes[:n, 6])
+        rb[:, 7] = torch.sin(gt_boxes[:n, 6])
+        if gt_boxes.shape[1] > 8:
+            rb[:, 8:] = gt_boxes[:n, 7:-1]
+        ret_boxes[:n] = torch.where(okf[:, None], rb, ret_boxes[:n])
+        gt_box[:n, :7] = torch.where(okf[:, None], gt_boxes[:n, :7], gt_box[:n, :7])
+        return heatmap, ret_boxes, inds, mask, gt_box
+
+    def assign_targets(self, gt_boxes, feature_map_size=None, **kwargs):
+        """gt_boxes (B, M, 10).  Computed on the host like the reference (radar_center_head.py:189-252) but from a host copy
+        of the boxes when the caller provides one (`gt_boxes_host`), so no device->host sync is needed; the result is
+        uploaded once per head.  The reference's in-place rewrite of the class column is applied to a clone."""
+        feature_map_size = feature_map_size[::-1]
+        cfg = self.model_cfg.TARGET_ASSIGNER_CONFIG
+        host = kwargs.get('gt_boxes_host', None)
+        dev = gt_boxes.device
+        gt_cpu = torch.as_tensor(host).float().clone() if host is not None else gt_boxes.detach().cpu().clone()
+        batch_size = gt_cpu.shape[0]
+        ret_dict = {'heatmaps': [], 'target_boxes': [], 'inds': [], 'masks': [], 'heatmap_masks': [], 'gt_box': []}
+        cls_all = gt_cpu[:, :, -1].long()
+        name_to_global = {n: i + 1 for i, n in enumerate(self.class_names)}
+        for cur_class_names in self.class_names_each_head:
+            ids = torch.tensor([name_to_global[n] for n in cur_class_names])
+            lists = [[], [], [], [], []]
+            for bs_idx in range(batch_size):
+                cur = gt_cpu[bs_idx]
+                c = cls_all[bs_idx]
+                sel = (c[:, None] == ids[None, :])
+                keep = sel.any(1)
+                single = cur[keep].clone()
+                single[:, -1] = (sel[keep].float().argmax(1) + 1).float()
+                out = self.assign_target_of_single_head(
+                    num_classes=len(cur_class_names), gt_boxes=single, feature_map_size=feature_map_size,
+                    feature_map_stride=cfg.FEATURE_MAP_STRIDE, num_max_objs=cfg.NUM_MAX_OBJS,
+                    gaussian_overlap=cfg.GAUSSIAN_OVERLAP, min_radius=cfg.MIN_RADIUS)
+                for l, o in zip(lists, out):
+                    l.append(o)
+            for key, l in zip(('heatmaps', 'target_boxes', 'inds', 'masks', 'gt_box'), lists):
+                ret_dict[key].append(torch.stack(l, dim=0).to(dev, non_blocking=True))
+        return ret_dict
+
+    def sigmoid(self, x):
+        return torch.clamp(x.sigmoid(), min=1e-4, max=1 - 1e-4)
+
+    # ------------------------------------------------------------------ loss
+    def get_loss(self):
+        pred_dicts = self.forward_ret_dict['pred_dicts']
+        target_dicts = self.forward_ret_dict['target_dicts']
+        tb_dict = {}
+        loss = 0
+        lw = self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS
+        for idx, pred_dict in enumerate(pred_dicts):
+            hm = self.sigmoid(pred_dict['hm'])
+            hm_loss = self.hm_loss_func(hm, target_dicts['heatmaps'][idx]) * lw['cls_weight']
+            target_boxes = target_dicts['target_boxes'][idx]
+            pred_boxes = torch.cat([pred_dict[head_name] for head_name in self.separate_head_cfg.HEAD_ORDER], dim=1)
+            if self.with_iou and self.with_iou_reg:
+                pred_boxes = pred_boxes[:, :-1, :, :]
+            reg_loss = self.reg_loss_func(pred_boxes, target_dicts['masks'][idx], target_dicts['inds'][idx], target_boxes)
+            loc_loss = (reg_loss * reg_loss.new_tensor(lw['code_weights'])).sum() * lw['loc_weight']
+            loss = loss + hm_loss + loc_loss
+            tb_dict['hm_loss_head_%d' % idx] = hm_loss.detach()
+            tb_dict['loc_loss_head_%d' % idx] = loc_loss.detach()
+            if self.with_iou or self.with_iou_reg:
+                batch_dim = torch.exp(torch.clamp(pred_dict['dim'], min=-5, max=5))
+                batch_rot = torch.atan2(pred_dict['rot'][:, 1:2], pred_dict['rot'][:, 0:1])
+                B, _, H, W = batch_dim.shape
+                ys, xs = torch.meshgrid(torch.arange(0, H, device=batch_dim.device), torch.arange(0, W, device=batch_dim.device), indexing='ij')
+                xs = xs.view(1, 1, H, W).to(batch_dim) + pred_dict['center'][:, 0:1]
+                ys = ys.view(1, 1, H, W).to(batch_dim) + pred_dict['center'][:, 1:2]
+                # parity trap kept: int() truncates the range origin (radar_center_head.py:309-310)
+                xs = xs * int(self.feature_map_stride) * self.voxel_size[0] + int(self.point_cloud_range[0])
+                ys = ys * int(self.feature_map_stride) * self.voxel_size[1] + int(self.point_cloud_range[1])
+                batch_box_preds = torch.cat([xs, ys, pred_dict['center_z'], batch_dim, batch_rot], dim=1)
+                if self.with_iou:
+                    iou_loss = self.crit_iou(pred_dict['iou'], target_dicts['masks'][idx], target_dicts['inds'][idx],
+                                             batch_box_preds.detach(), target_dicts['gt_box'][idx])
+                    loss = loss + iou_loss
+                    tb_dict['iou_loss_head_%d' % idx] = iou_loss.detach()
+                if self.with_iou_reg:
+                    iou_reg_loss = self.crit_iou_reg(batch_box_preds, target_dicts['masks'][idx], target_dicts['inds'][idx],
+                                                     target_dicts['gt_box'][idx])
+                    loss = loss + lw['loc_weight'] * iou_reg_loss
+                    tb_dict['iou_reg_loss_head_%d' % idx] = iou_reg_loss.detach()
+        tb_dict['rpn_loss'] = loss.detach()
+        return loss, tb_dict
+
+    def generate_predicted_boxes(self, batch_size, pred_dicts):
+        raise NotImplementedError("eval-time decode + rotated NMS is a 'next' row (SURVEY 8(f) rank 2), not on the training hot path")
+
+    # ------------------------------------------------------------------ forward
+    def head_forward(self, spatial_features_2d):
+        x = D.conv_bn_act(spatial_features_2d, self.shared_conv[0], self.shared_conv[1], None, act=1, return_rows=True)
+        return [head(x) for head in self.heads_list]
+
+    def forward(self, data_dict):
+        spatial_features_2d = data_dict[self.FEATURE_KEY]
+        pred_dicts = self.head_forward(spatial_features_2d)
+        if self.training:
+            target_dict = self.assign_targets(data_dict['gt_boxes'], feature_map_size=spatial_features_2d.size()[2:],
+                                              gt_boxes_host=data_dict.get('gt_boxes_host', None))
+            self.forward_ret_dict['target_dicts'] = target_dict
+            if self.model_cfg.get('DISTILL_PRED', None) and not self.IS_TEACHER:
+                data_dict['target_dicts'] = target_dict
+                data_dict['radar_pred_dicts'] = pred_dicts
+        if self.IS_TEACHER and self.model_cfg.get('DISTILL_PRED', None):       # center_head.py:403-406
+            data_dict['lidar_pred_dicts'] = pred_dicts
+            return data_dict
+        self.forward_ret_dict['pred_dicts'] = pred_dicts
+        if not self.training or self.predict_boxes_when_training:
+            raise NotImplementedError("inference decode / ROI refinement are not part of the distill training path")
+        return data_dict

@@ -1,0 +1,59 @@
+"""PillarNet with the distillation branches (pcdet/models/detectors/pillarnet.py:12-96): freeze list by class name,
+module chain over a shared batch_dict, three loss modes."""
+import torch
+
+from .detector3d_template import Detector3DTemplate
+
+
+class PillarNet(Detector3DTemplate):
+    def __init__(self, model_cfg, num_class, dataset):
+        super().__init__(model_cfg=model_cfg, num_class=num_class, dataset=dataset)
+        self.module_list = self.build_networks()
+        self.model_cfg = model_cfg
+        if self.model_cfg.get('FREEZE_PIPELINE', None) is not None:
+            self.no_grad_module = model_cfg['FREEZE_PIPELINE']
+            for cur_module in self.module_list:
+                if cur_module.__class__.__name__ in self.no_grad_module:
+                    for param in cur_module.parameters():
+                        param.requires_grad = False
+        else:
+            self.no_grad_module = []
+        # The frozen teacher CenterHead's predictions (`lidar_pred_dicts`) are consumed by nothing in the distill loss
+        # (pillarnet.py:65-73).  Kept on by default for fidelity; MODEL.SKIP_UNUSED_TEACHER_HEAD: True drops that dead work.
+        self.skip_unused_teacher_head = bool(self.model_cfg.get('SKIP_UNUSED_TEACHER_HEAD', False))
+
+    def forward(self, batch_dict):
+        for cur_module in self.module_list:
+            cur_name = cur_module.__class__.__name__
+            if cur_name in self.no_grad_module:
+                cur_module.eval()
+                if self.skip_unused_teacher_head and cur_name == 'CenterHead' and self.training:
+                    continue
+                with torch.no_grad():          # frozen modules: fused inference kernels, no autograd graph
+                    batch_dict = cur_module(batch_dict)
+            else:
+                batch_dict = cur_module(batch_dict)
+        if self.training:
+            if self.model_cfg.get('DISTILL', None) is None:
+                loss, tb_dict, disp_dict = self.get_training_loss()
+            elif self.model_cfg.get('DISTILL', None):
+                loss, tb_dict, disp_dict = self.get_training_distll_loss(batch_dict)
+            else:
+                loss, tb_dict, disp_dict = self.get_training_wo_distll_loss(batch_dict)
+            return {'loss': loss}, tb_dict, disp_dict
+        raise NotImplementedError("post_processing (eval decode + NMS + recall) is a 'next' row, SURVEY 8(f) rank 2")
+
+    def get_training_loss(self):
+        loss_rpn, tb_dict = self.dense_head.get_loss()
+        tb_dict = {'loss_rpn': loss_rpn.detach(), **tb_dict}
+        return loss_rpn, tb_dict, {}
+
+    def get_training_distll_loss(self, batch_dict):
+        loss_feature, tb_dict = self.radar_backbone_2d.get_loss(batch_dict)
+        loss_rpn, _tb_dict = self.radar_dense_head.get_loss()
+        tb_dict.update(_tb_dict)
+        return loss_feature + loss_rpn, tb_dict, {}
+
+    def get_training_wo_distll_loss(self, batch_dict):
+        loss_rpn, tb_dict = self.radar_dense_head.get_loss()
+        return loss_rpn, tb_dict, {}

@@ -4,7 +4,7 @@ from typing import Set
 
 import torch.nn as nn
 
-from ... import sparse as spconv
+from radardistill_amd import sparse as spconv
 
 
 def find_all_spconv_keys(model: nn.Module, prefix="") -> Set[str]:

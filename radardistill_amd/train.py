@@ -1,0 +1,150 @@
+"""Optimizer step + training-step driver of the hot path.
+
+Semantics of the reference loop (tools/train_utils/train_utils.py:44-64, optimization/__init__.py:19-54,
+fastai_optim.py:135-152, learning_schedules_fastai.py:44-77): OneCycle(lr_max, moms, div_factor, pct_start) sets lr and
+beta1 per iteration; zero_grad; forward; backward (DDP all-reduce overlapped); clip_grad_norm_(10); decoupled weight decay
+p *= 1 - wd*lr on EVERY trainable parameter (bn_wd=True); Adam(betas=(mom, 0.99), eps 1e-8).
+
+MI355X design: the ~500 parameter tensors are described by one device table; gradient norm and decay+Adam are two
+multi-tensor HIP launches (optim.hip), the clip coefficient never visits the host, Adam state lives in two flat buffers.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import autograd as A
+from . import native
+from .kernels import _p, _stream
+from .native import check
+
+
+def annealing_cos(start, end, pct):
+    return end + (start - end) / 2 * (math.cos(math.pi * pct) + 1)
+
+
+class OneCycle:
+    """lr / momentum phases of learning_schedules_fastai.py:60-77 (+ LRSchedulerStep.step :44-50)."""
+
+    def __init__(self, optimizer, total_step, lr_max, moms, div_factor, pct_start):
+        self.optimizer, self.total_step = optimizer, int(total_step)
+        self.lr_max, self.moms, self.div_factor, self.pct_start = lr_max, list(moms), div_factor, pct_start
+        low = lr_max / div_factor
+        p1 = int(self.total_step * pct_start)
+        self.lr_phases = [(0, p1, (low, lr_max)), (p1, self.total_step, (lr_max, low / 1e4))]
+        self.mom_phases = [(0, p1, (self.moms[0], self.moms[1])), (p1, self.total_step, (self.moms[1], self.moms[0]))]
+        optimizer.lr, optimizer.mom = low, self.moms[0]
+
+    def step(self, step, epoch=None):
+        for s, e, (a, b) in self.lr_phases:
+            if step >= s:
+                self.optimizer.lr = annealing_cos(a, b, (step - s) / (e - s))
+        for s, e, (a, b) in self.mom_phases:
+            if step >= s:
+                self.optimizer.mom = annealing_cos(a, b, (step - s) / (e - s))
+
+
+class _OptTensor(ctypes.Structure):
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p),
+                ("exp_avg_sq", ctypes.c_void_p), ("numel", ctypes.c_int64)]
+
+
+class FusedAdamOneCycle:
+    """`adam_onecycle` optimizer of the reference (OptimWrapper over Adam with true_wd, bn_wd) as fused HIP launches."""
+
+    def __init__(self, params, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, wd=0.01, grad_clip=10.0):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        for p in self.params:
+            if p.dtype != torch.float32 or not p.is_contiguous() or p.device != dev:
+                raise RuntimeError("FusedAdamOneCycle needs contiguous fp32 parameters on one device")
+        self.lr, self.mom, self.beta2, self.eps, self.wd, self.grad_clip = lr, betas[0], betas[1], eps, wd, grad_clip
+        self.step_count = 0
+        n = sum(p.numel() for p in self.params)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.offsets = np.cumsum([0] + [p.numel() for p in self.params])
+        chunk = native.lib().rd_opt_chunk_elems()
+        chunks = []
+        for i, p in enumerate(self.params):
+            for off in range(0, p.numel(), chunk):
+                chunks.append((i, off))
+        self.n_chunks = len(chunks)
+        self.chunks_dev = torch.tensor(chunks, dtype=torch.int32, device=dev).contiguous()
+        self.table_host = torch.empty(len(self.params) * ctypes.sizeof(_OptTensor), dtype=torch.uint8).pin_memory() \
+            if dev.type == "cuda" else torch.empty(len(self.params) * ctypes.sizeof(_OptTensor), dtype=torch.uint8)
+        self.table_dev = torch.empty_like(self.table_host, device=dev)
+        self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.ws = torch.empty(self.n_chunks, dtype=torch.float32, device=dev)
+        self._zero = {}
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def _fill_table(self):
+        arr = (_OptTensor * len(self.params)).from_buffer(self.table_host.numpy())
+        m0, v0 = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
+        for i, p in enumerate(self.params):
+            g = p.grad
+            if g is None:                      # parameter unused this step: zero gradient (Adam still decays its moments)
+                g = self._zero.get(i)
+                if g is None:
+                    g = self._zero[i] = torch.zeros_like(p)
+            elif not g.is_contiguous() or g.dtype != torch.float32:
+                g = p.grad = g.float().contiguous()
+            arr[i].param = p.data_ptr()
+            arr[i].grad = g.data_ptr()
+            arr[i].exp_avg = m0 + 4 * int(self.offsets[i])
+            arr[i].exp_avg_sq = v0 + 4 * int(self.offsets[i])
+            arr[i].numel = p.numel()
+        self.table_dev.copy_(self.table_host, non_blocking=True)
+
+    def step(self):
+        """clip_grad_norm_(grad_clip) + OptimWrapper.step(); returns the device tensor [total_norm, clip_coef]."""
+        self._fill_table()
+        L = native.lib()
+        clip = None
+        if self.grad_clip is not None and self.grad_clip > 0:
+            check(L.rd_grad_norm(_p(self.table_dev), _p(self.chunks_dev), self.n_chunks, float(self.grad_clip), _p(self.norm_out),
+                                 _p(self.ws), self.ws.numel() * 4, _stream()), "rd_grad_norm")
+            clip = self.norm_out
+        self.step_count += 1
+        check(L.rd_adam_step(_p(self.table_dev), _p(self.chunks_dev), self.n_chunks, float(self.lr), float(self.mom), float(self.beta2),
+                             float(self.eps), float(self.wd), self.step_count, _p(clip), _stream()), "rd_adam_step")
+        A.bump_weights_epoch()                 # parameters changed through raw pointers: invalidate cached weight layouts
+        return self.norm_out
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr, "mom": self.mom}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.lr, self.mom = sd["lr"], sd["mom"]
+
+
+def build_optimizer(model, optim_cfg):
+    if optim_cfg.OPTIMIZER != 'adam_onecycle':
+        raise NotImplementedError("the distill config trains with adam_onecycle")
+    betas = tuple(optim_cfg.get('BETAS', (0.9, 0.99)))
+    return FusedAdamOneCycle(model.parameters(), lr=3e-3, betas=betas, wd=optim_cfg.WEIGHT_DECAY, grad_clip=optim_cfg.GRAD_NORM_CLIP)
+
+
+def build_scheduler(optimizer, total_iters_each_epoch, total_epochs, last_epoch, optim_cfg):
+    total_steps = total_iters_each_epoch * total_epochs
+    return OneCycle(optimizer, total_steps, optim_cfg.LR, list(optim_cfg.MOMS), optim_cfg.DIV_FACTOR, optim_cfg.PCT_START), None
+
+
+def train_step(model, optimizer, lr_scheduler, model_func, batch, accumulated_iter):
+    """One iteration of train_one_epoch (train_utils.py:44-64) without logging: returns (loss tensor, tb_dict)."""
+    lr_scheduler.step(accumulated_iter)
+    model.train()
+    optimizer.zero_grad()
+    loss, tb_dict, disp_dict = model_func(model, batch)
+    loss.backward()
+    optimizer.step()
+    return loss, tb_dict

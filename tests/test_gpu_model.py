@@ -1,0 +1,299 @@
+"""GPU parity tests, part 2: DCNv2, AFD/PFD, rotated overlap, optimizer, the 2-D modules against the golden fixtures
+generated from the reference's own modules, and the whole PillarNet distillation step against the CPU oracle."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import bev as obev, head as ohead, optim as ooptim, pillarnet as opn      # noqa: E402  (checker only)
+from radardistill_amd.synthetic import bench_geometry, make_batch                       # noqa: E402
+from tests.seeded import seeded_fill_                                                   # noqa: E402
+from tests.test_gpu_kernels import close, DEV                                           # noqa: E402
+
+BEV_CFG = dict(LAYER_NUMS=[5, 5], LAYER_STRIDES=[1, 2], NUM_FILTERS=[256, 256], UPSAMPLE_STRIDES=[1, 2], NUM_UPSAMPLE_FILTERS=[128, 128])
+
+
+def _cl(x):
+    return x.to(DEV).contiguous(memory_format=torch.channels_last)
+
+
+def _bev_inputs(seed, B=1, S=16):
+    g = np.random.default_rng(seed)
+    x4 = g.normal(0, 1, size=(B, 256, S, S)).astype(np.float32)
+    x4 *= (g.uniform(size=(B, 1, S, S)) < 0.4)
+    x5 = g.normal(0, 1, size=(B, 256, S // 2, S // 2)).astype(np.float32)
+    return torch.from_numpy(x4), torch.from_numpy(x5)
+
+
+# ------------------------------------------------------------------------------------------ DCNv2
+@pytest.mark.parametrize("C,Cout,H,W,stride", [(64, 64, 9, 8, 2), (32, 96, 7, 7, 1), (256, 256, 16, 16, 2)])
+def test_dcn_forward_backward_vs_oracle(C, Cout, H, W, stride):
+    from radardistill_amd.pcdet.ops.basicblock.modulated_deform_conv import ModulatedDeformConv
+    rng = np.random.default_rng(C + H)
+    B = 2
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    x = torch.from_numpy(rng.normal(size=(B, C, H, W)).astype(np.float32))
+    off = torch.from_numpy((rng.normal(size=(B, 18, Ho, Wo)) * 1.5).astype(np.float32))
+    off[0, :, 0, 0] = -3.0          # samples far outside the map
+    off[1, 0::2, -1, -1] = 0.0      # exactly integer positions
+    mask = torch.from_numpy(rng.uniform(0, 1, size=(B, 9, Ho, Wo)).astype(np.float32))
+    m = ModulatedDeformConv(C, Cout, 3, stride, 1, bias=False)
+    w, b = m.weight.detach().clone(), m.bias.detach().clone()
+    xr, offr, mr, wr = [t.clone().requires_grad_(True) for t in (x, off, mask, w)]
+    ref = obev.modulated_deform_conv(xr, offr, mr, wr, b, stride=stride, pad=1)
+    go = torch.from_numpy(rng.normal(size=tuple(ref.shape)).astype(np.float32))
+    (ref * go).sum().backward()
+    md = m.to(DEV)
+    xd, offd, maskd = [t.to(DEV).requires_grad_(True) for t in (x, off, mask)]
+    out = md(xd, offd, maskd)
+    close(out, ref, what="dcn fwd")
+    (out * go.to(DEV)).sum().backward()
+    close(xd.grad, xr.grad, atol=2e-4, what="dcn grad input")
+    close(offd.grad, offr.grad, atol=3e-4, what="dcn grad offset")
+    close(maskd.grad, mr.grad, atol=2e-4, what="dcn grad mask")
+    close(md.weight.grad, wr.grad, atol=2e-4, what="dcn grad weight")
+    assert md.bias.grad is None                       # bias=False: parameter exists, is added, but stays frozen
+
+
+def test_dcn_zero_offset_unit_mask_is_conv2d():
+    """Known answer restated from the reference's pcdet/ops/basicblock/test.py:69-110."""
+    from radardistill_amd.pcdet.ops.basicblock.modulated_deform_conv import ModulatedDeformConv
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 64, 10, 12, generator=g)
+    m = ModulatedDeformConv(64, 32, 3, 2, 1, bias=True)
+    ref = F.conv2d(x, m.weight, m.bias, stride=2, padding=1)
+    md = copy.deepcopy(m).to(DEV)
+    out = md(x.to(DEV), torch.zeros(2, 18, 5, 6, device=DEV), torch.ones(2, 9, 5, 6, device=DEV))
+    close(out, ref, rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------ AFD / PFD
+def _radar_distill(seed=13):
+    from radardistill_amd.pcdet.config import AttrDict
+    from radardistill_amd.pcdet.models.backbones_2d import __all__ as REG
+    cfg = AttrDict(dict(BEV_CFG, VOXEL_SIZE=[0.2, 0.2, 8.0], POINT_CLOUD_RANGE=[-12.8, -12.8, -5, 12.8, 12.8, 3]))
+    m = REG["Radar_Distill"](cfg, input_channels=256)
+    sd = m.state_dict(); seeded_fill_(sd, seed=seed); m.load_state_dict(sd)
+    return m.to(DEV)
+
+
+def test_afd_pfd_golden_and_gradients(golden_dir):
+    g = np.load(f"{golden_dir}/g3_radar_distill.npz")
+    m = _radar_distill()
+    r = np.random.default_rng(23)
+    lid = torch.from_numpy(r.normal(0.2, 1, size=(2, 256, 16, 16)).astype(np.float32)) * \
+        torch.from_numpy((r.uniform(size=(2, 1, 16, 16)) < 0.5).astype(np.float32))
+    rad = torch.from_numpy(r.normal(0.0, 1, size=(2, 256, 16, 16)).astype(np.float32))
+    f, ml = m.low_loss(_cl(lid), _cl(rad))
+    close(f, g["afd_feature"], rtol=1e-3, atol=1e-6); close(ml, g["afd_mask"], rtol=1e-3, atol=1e-6)
+    f2, _ = m.low_loss(_cl(lid.abs() + 1.0), _cl(rad))
+    assert torch.isnan(f2).item() and np.isnan(g["afd_feature_nan"])                   # the reference's 0*inf edge case
+    hms = [torch.from_numpy(r.uniform(0, 1, size=(2, c, 16, 16)).astype(np.float32) ** 6) for c in (1, 2, 2, 1, 2, 2)]
+    logits = [torch.from_numpy(r.normal(-2.0, 1.5, size=(2, c, 16, 16)).astype(np.float32)) for c in (1, 2, 2, 1, 2, 2)]
+    r1, r2, l1, l2 = [torch.from_numpy(r.normal(0, 1, size=(2, 256, 16, 16)).astype(np.float32)) for _ in range(4)]
+    pfd = m.high_loss(_cl(r1), _cl(r2), _cl(l1), _cl(l2), [h.to(DEV) for h in hms], [{"hm": h.to(DEV)} for h in logits])
+    close(pfd, g["pfd"], rtol=1e-3, atol=1e-6)
+    # get_loss total + every tb entry, and gradients w.r.t. the four radar maps vs oracle autograd
+    rd, r1d, r2d = [_cl(t).requires_grad_(True) for t in (rad, r1, r2)]
+    bd = {"multi_scale_2d_features": {"x_conv4": _cl(lid)},
+          "radar_multi_scale_2d_features": {"radar_spatial_features_8x_2": rd, "radar_spatial_features_8x_1": r1d},
+          "radar_spatial_features_2d": r1d, "spatial_features_2d": _cl(l1),
+          "radar_spatial_features_2d_8x": r2d, "spatial_features_2d_8x": _cl(l2),
+          "radar_pred_dicts": [{"hm": h.to(DEV)} for h in logits], "target_dicts": {"heatmaps": [h.to(DEV) for h in hms]}}
+    total, tb = m.get_loss(bd)
+    close(total, g["get_loss_total"], rtol=1e-3, atol=1e-6)
+    for k, v in tb.items():
+        close(v, g["tb_" + k], rtol=1e-3, atol=1e-6, what=k)
+    total.backward()
+    ro, r1o, r2o = [t.clone().requires_grad_(True) for t in (rad, r1, r2)]
+    tot_o, _ = obev.distill_loss(lid, {"radar_spatial_features_8x_2": ro, "radar_spatial_features_8x_1": r1o,
+                                       "radar_spatial_features_2d": r1o, "radar_spatial_features_2d_8x": r2o}, l1, l2, hms, logits)
+    tot_o.backward()
+    close(rd.grad, ro.grad, atol=2e-4, what="grad 8x_2"); close(r1d.grad, r1o.grad, atol=2e-4, what="grad 8x_1 + 2d")
+    close(r2d.grad, r2o.grad, atol=2e-4, what="grad 2d_8x")
+
+
+# ------------------------------------------------------------------------------------------ rotated overlap
+def test_rotated_overlap_vs_oracle_and_known_answers():
+    from radardistill_amd import kernels as K
+    rng = np.random.default_rng(3)
+    n = 4000
+    a = np.concatenate([rng.uniform(-20, 20, (n, 3)), rng.uniform(0.3, 8, (n, 3)), rng.uniform(-np.pi, np.pi, (n, 1))], 1).astype(np.float32)
+    b = a.copy()
+    b[:, :2] += rng.normal(0, 1.0, (n, 2)).astype(np.float32); b[:, 3:6] *= rng.uniform(0.7, 1.3, (n, 3)).astype(np.float32)
+    b[:, 6] += rng.normal(0, 0.4, n).astype(np.float32)
+    b[:50] = a[:50]                                        # identical boxes
+    b[50:100, 0] += 100.0                                  # disjoint
+    out = K.boxes_aligned_overlap_bev(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV)).view(-1).cpu().numpy()
+    ref = ohead.boxes_aligned_overlap_bev(torch.from_numpy(a), torch.from_numpy(b)).numpy()
+    # same algorithm, same fp32 operation order: agree to rounding of sin/cos/atan2 implementations
+    np.testing.assert_allclose(out, ref, rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(out[:50], a[:50, 3] * a[:50, 4], rtol=1e-3)
+    assert np.all(out[50:100] == 0)
+    from radardistill_amd.pcdet.ops.iou3d_nms.iou3d_nms_utils import boxes_aligned_iou3d_gpu
+    iou = boxes_aligned_iou3d_gpu(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV)).cpu()
+    close(iou, ohead.boxes_aligned_iou3d(torch.from_numpy(a), torch.from_numpy(b)), rtol=2e-3, atol=2e-3)
+
+
+# ------------------------------------------------------------------------------------------ optimizer
+def test_fused_adam_onecycle_matches_oracle():
+    from radardistill_amd.train import FusedAdamOneCycle, OneCycle
+    rng = np.random.default_rng(0)
+    shapes = [(300,), (64, 3, 3, 32), (5000, 7), (1,), (4097,)]
+    ps = [torch.nn.Parameter(torch.from_numpy(rng.normal(size=s).astype(np.float32)).to(DEV)) for s in shapes]
+    ref_p = [p.detach().cpu().clone() for p in ps]
+    m = [torch.zeros_like(p) for p in ref_p]; v = [torch.zeros_like(p) for p in ref_p]
+    opt = FusedAdamOneCycle(ps, wd=0.01, grad_clip=10.0)
+    sched = OneCycle(opt, 1000, 1e-3, [0.95, 0.85], 10, 0.4)
+    for it in range(4):
+        sched.step(it * 150)
+        lr, mom = ooptim.one_cycle(it * 150, 1000)
+        assert abs(opt.lr - lr) < 1e-12 and abs(opt.mom - mom) < 1e-12
+        grads = [torch.from_numpy((rng.normal(size=s) * (30.0 if it == 1 else 0.5)).astype(np.float32)) for s in shapes]
+        for p, g in zip(ps, grads):
+            p.grad = g.to(DEV)
+        norm = opt.step()
+        total, clipped = ooptim.clip_grad_norm(grads, 10.0)
+        close(norm[0], total, rtol=1e-5)
+        ooptim.adam_true_wd_step(ref_p, clipped, m, v, it + 1, lr, mom)
+        for a, b in zip(ps, ref_p):
+            close(a, b, rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------ goldens of the 2-D modules
+def test_dense_enc_golden(golden_dir):
+    from radardistill_amd.pcdet.config import AttrDict
+    from radardistill_amd.pcdet.models.backbones_2d import __all__ as REG
+    g = np.load(f"{golden_dir}/g2_dense_enc.npz")
+    m = REG["BaseBEVBackboneV2"](AttrDict(BEV_CFG), input_channels=256)
+    sd = m.state_dict(); seeded_fill_(sd, seed=12); m.load_state_dict(sd); m = m.to(DEV)
+    x4, x5 = _bev_inputs(21)
+    for mode in ("eval", "train"):
+        m.train(mode == "train")
+        with torch.no_grad():
+            d = m({"multi_scale_2d_features": {"x_conv4": _cl(x4), "x_conv5": _cl(x5)}})
+        close(d["spatial_features_2d_8x"], g[f"{mode}_2d_8x"], what=mode); close(d["spatial_features_2d"], g[f"{mode}_2d"], what=mode)
+
+
+def test_radar_distill_forward_golden(golden_dir):
+    g = np.load(f"{golden_dir}/g3_radar_distill.npz")
+    m = _radar_distill()
+    x4, x5 = _bev_inputs(22, B=2)
+    for mode in ("eval", "train"):
+        m.train(mode == "train")
+        with torch.no_grad():
+            d = m({"radar_multi_scale_2d_features": {"x_conv4": _cl(x4), "x_conv5": _cl(x5)}})
+        ms = d["radar_multi_scale_2d_features"]
+        close(ms["radar_spatial_features_8x_2"], g[f"{mode}_8x_2"], what=mode); close(ms["radar_spatial_features_8x_1"], g[f"{mode}_8x_1"], what=mode)
+        close(d["radar_spatial_features_2d_8x"], g[f"{mode}_2d_8x"], what=mode); close(d["radar_spatial_features_2d"], g[f"{mode}_2d"], what=mode)
+
+
+def _head(seed=14, grid=128):
+    from radardistill_amd.pcdet.config import AttrDict
+    from radardistill_amd.pcdet.models.dense_heads import __all__ as REG
+    from tests.golden.make_golden import HEAD_CFG, CLASS_NAMES
+    pc_range, voxel, gs = bench_geometry(grid)
+    m = REG["Radar_CenterHead"](AttrDict(HEAD_CFG), input_channels=256, num_class=10, class_names=CLASS_NAMES, grid_size=gs,
+                                point_cloud_range=pc_range, voxel_size=voxel, predict_boxes_when_training=False)
+    sd = m.state_dict(); seeded_fill_(sd, seed=seed); m.load_state_dict(sd)
+    return m.to(DEV)
+
+
+def test_center_head_golden(golden_dir):
+    g = np.load(f"{golden_dir}/g4_center_head.npz")
+    m = _head()
+    r = np.random.default_rng(24)
+    feat = torch.from_numpy(r.normal(0, 1, size=(2, 256, 16, 16)).astype(np.float32))
+    gt = torch.from_numpy(g["gt_boxes"])
+    m.train()
+    d = m({"radar_spatial_features_2d": _cl(feat), "gt_boxes": gt.to(DEV), "gt_boxes_host": g["gt_boxes"], "batch_size": 2})
+    for h, pd in enumerate(d["radar_pred_dicts"]):
+        for k, v in pd.items():
+            close(v, g[f"pred_{h}_{k}"], what=f"pred {h} {k}")
+    td = d["target_dicts"]
+    for h in range(6):
+        assert np.array_equal(td["heatmaps"][h].cpu().numpy(), g[f"hm_{h}"])              # exact
+        assert np.array_equal(td["target_boxes"][h].cpu().numpy(), g[f"tb_{h}"])
+        assert np.array_equal(td["inds"][h].cpu().numpy(), g[f"ind_{h}"])
+        assert np.array_equal(td["masks"][h].cpu().numpy(), g[f"mask_{h}"])
+        assert np.array_equal(td["gt_box"][h].cpu().numpy(), g[f"gtbox_{h}"])
+    loss, tb = m.get_loss()
+    close(loss, g["loss"], rtol=1e-3, atol=1e-5)
+    for k, v in tb.items():
+        close(v, g["tb_" + k], rtol=1e-3, atol=1e-5, what=k)
+
+
+def test_conv5_golden(golden_dir):
+    from functools import partial
+    from radardistill_amd.pcdet.models.backbones_3d.spconv_backbone_2d import BasicBlock, post_act_block_dense
+    g = np.load(f"{golden_dir}/g5_conv5.npz")
+    norm = partial(torch.nn.BatchNorm2d, eps=1e-3, momentum=0.01)
+    m = torch.nn.Sequential(post_act_block_dense(256, 256, 3, norm_fn=norm, stride=2, padding=1), BasicBlock(256, 256, norm_fn=norm),
+                            BasicBlock(256, 256, norm_fn=norm))
+    sd = m.state_dict(); seeded_fill_(sd, seed=15); m.load_state_dict(sd); m = m.to(DEV)
+    x4, _ = _bev_inputs(25)
+    for mode in ("eval", "train"):
+        m.train(mode == "train")
+        with torch.no_grad():
+            close(m(_cl(x4)), g[f"{mode}_x_conv5"], what=mode)
+
+
+# ------------------------------------------------------------------------------------------ whole step vs oracle
+def _build_pillarnet(grid):
+    from radardistill_amd.data import SyntheticDistillDataset
+    from radardistill_amd.pcdet.config import AttrDict, cfg_from_yaml_file
+    from radardistill_amd.pcdet.models import build_network
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    c = cfg_from_yaml_file(os.path.join(root, "tools/cfgs/radar_distill/bench_512.yaml"), AttrDict())
+    pc_range, voxel, gs = bench_geometry(grid)
+    c.DATA_CONFIG.POINT_CLOUD_RANGE = pc_range
+    c.MODEL.RADAR_BACKBONE_2D.POINT_CLOUD_RANGE = pc_range
+    ds = SyntheticDistillDataset.from_cfg(c)
+    torch.manual_seed(0)
+    m = build_network(model_cfg=c.MODEL, num_class=len(c.CLASS_NAMES), dataset=ds)
+    return m, c, pc_range, voxel, gs
+
+
+def test_full_distillation_step_vs_oracle():
+    """Config C4 at reduced size (128 x 128 BEV, B = 2): loss, every tb entry and the gradients of a training step."""
+    from radardistill_amd.pcdet.models import model_fn_decorator
+    grid, B = 128, 2
+    model, cfg, pc_range, voxel, gs = _build_pillarnet(grid)
+    sd = model.state_dict(); seeded_fill_(sd, seed=77); model.load_state_dict(sd)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    trainable = [k for k, p in model.named_parameters() if p.requires_grad]
+    for k in trainable:
+        state[k].requires_grad_(True)
+    model = model.to(DEV)
+    batch = make_batch(batch_size=B, n_lidar=300, n_radar=700, n_boxes=10, grid=grid, seed=5)   # sparse lidar: AFD is NaN by definition when every 8x cell is lidar-active
+    model.train()
+    loss, tb, _ = model_fn_decorator()(model, {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in batch.items()})
+    loss.backward()
+    ob = {"points": torch.from_numpy(batch["points"]), "radar_points": torch.from_numpy(batch["radar_points"]),
+          "gt_boxes": torch.from_numpy(batch["gt_boxes"]), "batch_size": B}
+    oloss, otb, inter = opn.forward_train(state, ob, pc_range, voxel, gs)
+    oloss = oloss.mean()
+    oloss.backward()
+    print("loss hip/oracle", float(loss), float(oloss))
+    close(loss, oloss, rtol=1e-3, atol=1e-5, what="total loss")
+    for k, v in otb.items():
+        close(tb[k], v, rtol=2e-3, atol=1e-5, what=k)
+    named = dict(model.named_parameters())
+    worst = ("", 0.0)
+    for k in trainable:
+        a, b = named[k].grad, state[k].grad
+        assert a is not None, k
+        if b is None:
+            b = torch.zeros_like(state[k])
+        denom = float(b.abs().max()) + 1e-7
+        err = float((a.detach().cpu() - b).abs().max()) / denom
+        if err > worst[1]:
+            worst = (k, err)
+        assert err < 2e-2, (k, err, denom)
+    print("worst relative gradient error", worst)
+    assert int(model.global_step) == 1
