@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""bench.py -- RadarDistill training hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (config.workload): BASELINE.json configs[3] -- the full RadarDistill training step (frozen LiDAR teacher forward,
+radar student forward + backward incl. CMA / AFD / PFD / CenterHead losses, grad clip + Adam) on synthetic nuScenes-shaped
+sweeps: 512 x 512 BEV (0.2 m pillars), 35k LiDAR + 2k radar points and 30 boxes per sample, 8 samples per GPU, fp32.
+A "step" = one such training iteration on one batch; inputs are resident in HBM before the timed region.  One process per
+GPU; N > 1 shards samples over ranks (weak scaling) with DDP gradient all-reduce over RCCL.
+Prints ONE JSON line on rank 0 (metric: samples/sec, whole job).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak (no xf32 on gfx950)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="samples per GPU (BATCH_SIZE_PER_GPU of the reference yaml)")
+    ap.add_argument("--grid", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-grid", type=int, default=512)
+    ap.add_argument("--cpu-baseline-batch", type=int, default=4)
+    return ap.parse_args()
+
+
+def build(cfg_path, grid, device):
+    from radardistill_amd.data import SyntheticDistillDataset
+    from radardistill_amd.pcdet.config import AttrDict, cfg_from_yaml_file
+    from radardistill_amd.pcdet.models import build_network
+    from radardistill_amd.synthetic import bench_geometry
+    cfg = cfg_from_yaml_file(cfg_path, AttrDict())
+    pc_range, voxel, gs = bench_geometry(grid)
+    cfg.DATA_CONFIG.POINT_CLOUD_RANGE = pc_range
+    cfg.MODEL.RADAR_BACKBONE_2D.POINT_CLOUD_RANGE = pc_range
+    ds = SyntheticDistillDataset.from_cfg(cfg)
+    torch.manual_seed(0)
+    model = build_network(model_cfg=cfg.MODEL, num_class=len(cfg.CLASS_NAMES), dataset=ds)
+    # non-trivial eval-mode BatchNorm for the frozen teacher: mean N(0, 0.1), var U(0.5, 1.5)
+    g = torch.Generator().manual_seed(1)
+    for name, buf in model.named_buffers():
+        if name.endswith("running_mean"):
+            buf.copy_(torch.randn(buf.shape, generator=g) * 0.1)
+        elif name.endswith("running_var"):
+            buf.copy_(torch.rand(buf.shape, generator=g) + 0.5)
+    return model.to(device), cfg, (pc_range, voxel, gs)
+
+
+def device_batch(batch, device):
+    out = {}
+    for k, v in batch.items():
+        if isinstance(v, np.ndarray):
+            out[k] = torch.from_numpy(v).float().to(device)
+        else:
+            out[k] = v
+    out["gt_boxes_host"] = batch["gt_boxes"]
+    return out
+
+
+def cpu_baseline(grid, B=4):
+    """The CPU oracle (a port: the reference itself cannot run here) timed on this host: one full training
+    forward + backward on a bounded sample (B samples) of the bench geometry.  Reported, never the target."""
+    from oracle import pillarnet as opn
+    model, cfg, (pc_range, voxel, gs) = build(os.path.join(ROOT, "tools/cfgs/radar_distill/bench_512.yaml"), grid, "cpu")
+    from radardistill_amd.synthetic import make_batch
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            state[k].requires_grad_(True)
+    b = make_batch(batch_size=B, n_lidar=35000, n_radar=2000, n_boxes=30, grid=grid, seed=0)
+    ob = {"points": torch.from_numpy(b["points"]), "radar_points": torch.from_numpy(b["radar_points"]),
+          "gt_boxes": torch.from_numpy(b["gt_boxes"]), "batch_size": B}
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    t0 = time.time()
+    loss, _, _ = opn.forward_train(state, ob, pc_range, voxel, gs)
+    loss.mean().backward()
+    dt = time.time() - t0
+    return {"value": round(B / dt, 4), "unit": "samples/sec", "cores": cores, "kind": "port",
+            "sample": f"1 training step (teacher fwd + student fwd/bwd, no optimizer) at B={B}, {grid}x{grid} BEV, 35k+2k points: {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=device)     # "nccl" is RCCL on ROCm
+    from radardistill_amd import kernels as K
+    from radardistill_amd import native
+    from radardistill_amd.pcdet.models import model_fn_decorator
+    from radardistill_amd.synthetic import make_batch
+    from radardistill_amd.train import build_optimizer, build_scheduler
+    if native.lib().rd_device_ok() != 1:
+        raise SystemExit("bench.py: no gfx950 device visible to librdamd.so")
+
+    model, cfg, geom = build(os.path.join(ROOT, "tools/cfgs/radar_distill/bench_512.yaml"), args.grid, device)
+    model.train()
+    optimizer = build_optimizer(model, cfg.OPTIMIZATION)
+    total_steps = args.steps + args.warmup
+    sched, _ = build_scheduler(optimizer, max(total_steps, 10), 1, -1, cfg.OPTIMIZATION)
+    run_model = model
+    if world > 1:
+        run_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])
+    model_func = model_fn_decorator()
+    # a few distinct batches per rank, resident in HBM before timing; sample sharding: seed depends on the rank
+    batches = [device_batch(make_batch(batch_size=args.batch, n_lidar=35000, n_radar=2000, n_boxes=30, grid=args.grid,
+                                       seed=1000 * rank + i), device) for i in range(2)]
+
+    def step(it):
+        sched.step(it)
+        run_model.train()
+        optimizer.zero_grad()
+        loss, tb, _ = model_func(run_model, dict(batches[it % len(batches)]))
+        loss.backward()
+        optimizer.step()
+        return loss
+
+    for it in range(args.warmup):
+        step(it)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    K.CONV_PROFILE = []
+    barrier()
+    t0 = time.perf_counter()
+    for it in range(args.warmup, args.warmup + args.steps):
+        loss = step(it)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, K.CONV_PROFILE = K.CONV_PROFILE, None
+    last_loss = float(loss)
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        samples = args.batch * world * args.steps
+        kernel_ms = [a.elapsed_time(b) for a, b, _ in prof]
+        flops = [f for _, _, f in prof]
+        n_launch = len(prof)
+        avg_ms = sum(kernel_ms) / max(n_launch, 1)
+        achieved = (sum(flops) / max(n_launch, 1)) / (avg_ms * 1e-3) / 1e12 if n_launch else 0.0
+        out = {
+            "metric": "samples/sec", "value": round(samples / dt, 3), "unit": "samples/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "RadarDistill full training step (BASELINE configs[3]): frozen LiDAR teacher fwd + radar student "
+                                   "fwd/bwd (VFE, SparseEnc, CMA+DCNv2, DenseEnc, CenterHead, AFD+PFD+detection losses) + clip + Adam",
+                       "bev": f"{args.grid}x{args.grid}", "pillar_m": 0.2, "lidar_pts": 35000, "radar_pts": 2000, "boxes": 30,
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "teacher_head": "computed (unused by the loss, as in the reference)", "final_loss": last_loss},
+            "roofline": {"bound": "mfma", "kernel": "k_conv_igemm<128,2,2,false> (dense 3x3/1x1/transposed conv, linear)",
+                         "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": n_launch // max(args.steps, 1), "avg_launch_ms": round(avg_ms, 4),
+                         "time_share_of_step": round(sum(kernel_ms) / (dt * 1e3), 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_grid, args.cpu_baseline_batch)
+            except Exception as e:                      # the baseline is a reported extra; never lose the GPU number to it
+                out["cpu_baseline"] = {"value": None, "unit": "samples/sec", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -154,6 +154,11 @@ def conv_index_dense(B, Hin, Win, Hout, Wout, KH, KW, stride, pad, transposed=Fa
     return ix
 
 
+# Optional per-launch timing hook used by bench.py for the roofline of the dominant kernel (k_conv_igemm<128,2,2,false>):
+# a list to which (start_event, end_event, algorithmic_flops) of every such launch is appended.  None = off (no overhead).
+CONV_PROFILE = None
+
+
 def conv_fwd(x, weight_k, taps, bias, out_rows, Cout, ix, scale=None, shift=None, residual=None, relu=False, stats=None, nbr_keepalive=None):
     """x (in_rows, Cin); weight_k (Cout, taps, Cin) kernel layout -> (out_rows, Cout)."""
     _chk(x, f32, "conv input", 2)
@@ -170,8 +175,15 @@ def conv_fwd(x, weight_k, taps, bias, out_rows, Cout, ix, scale=None, shift=None
     if residual is not None and (_chk(residual, f32, "residual").shape != (out_rows, Cout)):
         raise RuntimeError("conv residual shape mismatch")
     out = torch.empty((out_rows, Cout), dtype=f32, device=x.device)
+    prof = CONV_PROFILE is not None and Cout > 64 and ix.mode in (1, 2)      # the BN=128 dense-geometry instantiation
+    if prof:
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(native.lib().rd_conv_fwd(_p(x), in_rows, Cin, _p(weight_k), taps, _p(bias), _p(out), out_rows, Cout, ctypes.byref(ix),
                                    _p(scale), _p(shift), _p(residual), int(relu), _p(stats), _stream()), "rd_conv_fwd")
+    if prof:
+        e1.record()
+        CONV_PROFILE.append((e0, e1, 2.0 * out_rows * taps * Cin * Cout))
     return out
 
 

@@ -19,7 +19,7 @@ def load_data_to_gpu(batch_dict):
     for key, val in list(batch_dict.items()):
         if not isinstance(val, np.ndarray):
             continue
-        if key in ['frame_id', 'metadata', 'calib', 'image_paths', 'ori_shape', 'img_process_infos']:
+        if key in ['frame_id', 'metadata', 'calib', 'image_paths', 'ori_shape', 'img_process_infos', 'gt_boxes_host']:
             continue
         if key == 'gt_boxes':
             batch_dict['gt_boxes_host'] = val

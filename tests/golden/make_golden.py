@@ -28,7 +28,6 @@ from tests.seeded import seeded_fill_  # noqa: E402
 from radardistill_amd.synthetic import make_batch, bench_geometry  # noqa: E402
 from oracle import bev as obev, head as ohead  # noqa: E402
 
-torch.set_grad_enabled(False)
 torch.set_num_threads(4)
 
 
@@ -157,21 +156,7 @@ def g3_radar_distill():
     save("g3_radar_distill.npz", **out)
 
 
-HEAD_CFG = dict(
-    DISTILL_PRED=True, CLASS_AGNOSTIC=False, IOU_REG="DIoU",
-    CLASS_NAMES_EACH_HEAD=[["car"], ["truck", "construction_vehicle"], ["bus", "trailer"], ["barrier"],
-                           ["motorcycle", "bicycle"], ["pedestrian", "traffic_cone"]],
-    SHARED_CONV_CHANNEL=64, USE_BIAS_BEFORE_NORM=True, NUM_HM_CONV=2,
-    SEPARATE_HEAD_CFG=dict(HEAD_ORDER=["center", "center_z", "dim", "rot", "vel", "iou"],
-                           HEAD_DICT={k: dict(out_channels=v, num_conv=2) for k, v in
-                                      dict(center=2, center_z=1, dim=3, rot=2, vel=2, iou=1).items()}),
-    RECTIFIER=0.5,
-    TARGET_ASSIGNER_CONFIG=dict(FEATURE_MAP_STRIDE=8, NUM_MAX_OBJS=500, GAUSSIAN_OVERLAP=0.1, MIN_RADIUS=2),
-    LOSS_CONFIG=dict(LOSS_WEIGHTS=dict(cls_weight=1.0, loc_weight=0.25,
-                                       code_weights=[1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2, 1.0, 1.0])),
-)
-CLASS_NAMES = ["car", "truck", "construction_vehicle", "bus", "trailer", "barrier", "motorcycle", "bicycle",
-               "pedestrian", "traffic_cone"]
+from tests.golden.head_cfg import HEAD_CFG, CLASS_NAMES  # noqa: E402
 
 
 def g4_center_head():
@@ -229,6 +214,7 @@ def g5_conv5():
 
 
 if __name__ == "__main__":
+    torch.set_grad_enabled(False)
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
     fns = {"g1": g1_vfe, "g2": g2_dense_enc, "g3": g3_radar_distill, "g4": g4_center_head, "g5": g5_conv5}
     for w in which:

@@ -324,13 +324,16 @@ def test_sparse_enc_c2_vs_oracle(training):
         named = dict(("radar_vfe." + k, p) for k, p in vfe_m.named_parameters())
         named.update(("radar_backbone_3d." + k, p) for k, p in bb.named_parameters())
         worst = 0.0
+        gscale = max(float(st[k].grad.abs().max()) for k in params)
         for k in params:
             a, b = named[k].grad.detach().cpu(), st[k].grad
             denom = float(b.abs().max()) + 1e-6
-            worst = max(worst, float((a - b).abs().max()) / denom)
-            # gradients at the bottom of a 40-layer train-mode-BN stack: fp32 summation-order noise reaches a few 1e-3 of the
-            # tensor's max; features/losses are held to 1e-3 (north_star), deep gradients to 1e-2
-            assert float((a - b).abs().max()) <= 1e-2 * denom + 1e-5, (k, float((a - b).abs().max()), denom)
+            err = float((a - b).abs().max())
+            worst = max(worst, err / (denom + 1e-4 * gscale))
+            # Features / losses are held to 1e-3 (north_star).  Gradients at the bottom of a 40-layer train-mode-BN stack carry
+            # fp32 summation-order noise of a few 1e-3 of the tensor's max; conv biases in front of a BatchNorm have a TRUE
+            # gradient of exactly 0, so what both sides hold there is cancellation noise -> absolute floor tied to the global scale.
+            assert err <= 1e-2 * denom + 1e-4 * gscale, (k, err, denom, gscale)
         print("worst relative grad error", worst)
         # running statistics follow the reference's momentum update
         for k, v in bb.state_dict().items():

@@ -195,7 +195,7 @@ def test_radar_distill_forward_golden(golden_dir):
 def _head(seed=14, grid=128):
     from radardistill_amd.pcdet.config import AttrDict
     from radardistill_amd.pcdet.models.dense_heads import __all__ as REG
-    from tests.golden.make_golden import HEAD_CFG, CLASS_NAMES
+    from tests.golden.head_cfg import HEAD_CFG, CLASS_NAMES
     pc_range, voxel, gs = bench_geometry(grid)
     m = REG["Radar_CenterHead"](AttrDict(HEAD_CFG), input_channels=256, num_class=10, class_names=CLASS_NAMES, grid_size=gs,
                                 point_cloud_range=pc_range, voxel_size=voxel, predict_boxes_when_training=False)
@@ -217,7 +217,8 @@ def test_center_head_golden(golden_dir):
     td = d["target_dicts"]
     for h in range(6):
         assert np.array_equal(td["heatmaps"][h].cpu().numpy(), g[f"hm_{h}"])              # exact
-        assert np.array_equal(td["target_boxes"][h].cpu().numpy(), g[f"tb_{h}"])
+        # log / cos / sin of the box parameters run in torch-CPU on whatever host executes the test: allow 1 ulp of libm difference
+        np.testing.assert_allclose(td["target_boxes"][h].cpu().numpy(), g[f"tb_{h}"], rtol=1e-6, atol=1e-7)
         assert np.array_equal(td["inds"][h].cpu().numpy(), g[f"ind_{h}"])
         assert np.array_equal(td["masks"][h].cpu().numpy(), g[f"mask_{h}"])
         assert np.array_equal(td["gt_box"][h].cpu().numpy(), g[f"gtbox_{h}"])
@@ -285,15 +286,18 @@ def test_full_distillation_step_vs_oracle():
         close(tb[k], v, rtol=2e-3, atol=1e-5, what=k)
     named = dict(model.named_parameters())
     worst = ("", 0.0)
+    gscale = max(float(state[k].grad.abs().max()) for k in trainable if state[k].grad is not None)
     for k in trainable:
         a, b = named[k].grad, state[k].grad
         assert a is not None, k
         if b is None:
             b = torch.zeros_like(state[k])
-        denom = float(b.abs().max()) + 1e-7
-        err = float((a.detach().cpu() - b).abs().max()) / denom
-        if err > worst[1]:
-            worst = (k, err)
-        assert err < 2e-2, (k, err, denom)
+        denom = float(b.abs().max())
+        err = float((a.detach().cpu() - b).abs().max())
+        rel = err / (denom + 1e-4 * gscale)
+        if rel > worst[1]:
+            worst = (k, rel)
+        # see tests/test_gpu_kernels.py::test_sparse_enc_c2_vs_oracle for why gradients get 1e-2 + a global-scale floor
+        assert err <= 1e-2 * denom + 1e-4 * gscale, (k, err, denom, gscale)
     print("worst relative gradient error", worst)
     assert int(model.global_step) == 1
