@@ -85,7 +85,7 @@ def cpu_baseline(grid, B=4):
     b = make_batch(batch_size=B, n_lidar=35000, n_radar=2000, n_boxes=30, grid=grid, seed=0)
     ob = {"points": torch.from_numpy(b["points"]), "radar_points": torch.from_numpy(b["radar_points"]),
           "gt_boxes": torch.from_numpy(b["gt_boxes"]), "batch_size": B}
-    cores = os.cpu_count() or 1
+    cores = min(len(os.sched_getaffinity(0)), 16)      # the GPU box gives a 16-core share; cpu_count() reports the host
     torch.set_num_threads(cores)
     t0 = time.time()
     loss, _, _ = opn.forward_train(state, ob, pc_range, voxel, gs)
@@ -161,9 +161,17 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
+        print(f"[bench] {args.steps} steps in {dt:.3f} s on {world} GPU(s)", file=sys.stderr, flush=True)
         samples = args.batch * world * args.steps
-        kernel_ms = [a.elapsed_time(b) for a, b, _ in prof]
-        flops = [f for _, _, f in prof]
+        kernel_ms = [a.elapsed_time(b) for a, b, _, _, _ in prof]
+        flops = [(f if pairs is None else float(pairs.item()) * f) for _, _, pairs, f, _ in prof]
+        if os.environ.get("RD_BENCH_SHAPES"):
+            agg = {}
+            for ms, fl, (_, _, _, _, shape) in zip(kernel_ms, flops, prof):
+                a = agg.setdefault(shape, [0, 0.0, 0.0]); a[0] += 1; a[1] += ms; a[2] += fl
+            for shape, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                print(f"[shape in_rows,Cin,Cout,taps,mode={shape}] launches/step {n / args.steps:.1f} ms/step {ms / args.steps:.3f} "
+                      f"TF/s {fl / (ms * 1e-3) / 1e12:.1f}", file=sys.stderr)
         n_launch = len(prof)
         avg_ms = sum(kernel_ms) / max(n_launch, 1)
         achieved = (sum(flops) / max(n_launch, 1)) / (avg_ms * 1e-3) / 1e12 if n_launch else 0.0
@@ -186,7 +194,7 @@ def main():
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_grid, args.cpu_baseline_batch)
             except Exception as e:                      # the baseline is a reported extra; never lose the GPU number to it
-                out["cpu_baseline"] = {"value": None, "unit": "samples/sec", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+                out["cpu_baseline"] = {"value": None, "unit": "samples/sec", "cores": None, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

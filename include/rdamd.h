@@ -230,6 +230,17 @@ int rd_grad_norm(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, in
 int rd_adam_step(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int step, const float *clip_dev, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * J. Depthwise KxK convolution on channels-last maps (ConvNeXt dwconv 7x7, groups = C, padding K/2).  Replaces cuDNN's
+ *    depthwise conv2d in pcdet/ops/basicblock/modules/Basicblock_convn.py:13,47.  weight_tc is [K*K][C] (tap-major);
+ *    flip = 1 reads taps reversed (data gradient).  rd_dwconv_wgrad -> grad in the same [K*K][C] layout.
+ * ---------------------------------------------------------------------------------------------- */
+int rd_dwconv_fwd(const float *in, const float *weight_tc, const float *bias, int B, int H, int W, int C, int K, int flip, float *out,
+                  void *stream);
+int64_t rd_dwconv_wgrad_ws_bytes(int B, int H, int W, int C, int K);
+int rd_dwconv_wgrad(const float *in, const float *grad_out, int B, int H, int W, int C, int K, float *grad_w_tc, float *ws, int64_t ws_bytes,
+                    void *stream);
+
 #ifdef __cplusplus
 }
 #endif

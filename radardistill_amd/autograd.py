@@ -2,9 +2,21 @@
 north_star asks).  Each Function's forward and backward run hand-written kernels through the C ABI; torch only
 owns the tensors and the graph.
 """
+import os
+
 import torch
 
 from . import kernels as K
+
+_DEBUG = bool(int(os.environ.get("RD_DEBUG_CHECK", "0")))     # developer aid: re-derive backward results with torch ops and report mismatches
+
+
+def _dbg_report(name, got, ref):
+    err = float((got - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
+    if err > 1e-4:
+        d = (got - ref).abs().max(1)[0]
+        rows = torch.topk(d, min(5, d.numel())).indices.tolist()
+        print(f"[RD_DEBUG] {name}: rel err {err:.3e} worst rows {rows} of {got.shape}", flush=True)
 
 # bumped by the optimizer after every parameter update done through raw pointers (tensor._version does not see those)
 _WEIGHTS_EPOCH = [0]
@@ -100,6 +112,14 @@ class _ConvFn(torch.autograd.Function):
                 wk = torch.nn.functional.pad(wk.reshape(Cout, -1), (0, 0, 0, Cp - Cout))
             wd = K.weight_layout(wk.contiguous(), Cp, Cin, spec.taps, 2, False)          # [Cin][taps][Cout]
             gx = K.conv_fwd(go, wd, spec.taps, None, spec.in_rows, Cin, spec.bwd_ix, nbr_keepalive=spec.bwd_nbr)
+            if _DEBUG and spec.fwd_nbr is not None:
+                w3 = wk.reshape(-1, spec.taps, Cin)[:Cout].double()
+                ref = torch.zeros((spec.in_rows, Cin), dtype=torch.float64, device=x.device)
+                nb = spec.fwd_nbr.long()
+                for t in range(spec.taps):
+                    o = torch.nonzero(nb[:, t] >= 0).squeeze(1)
+                    ref.index_add_(0, nb[o, t], grad_out[o].double() @ w3[:, t, :])
+                _dbg_report(f"conv dgrad Cin={Cin} Cout={Cout} rows {spec.out_rows}->{spec.in_rows} flip={spec.bwd_ix.flip}", gx.double(), ref)
         if ctx.needs_input_grad[1]:
             gwk = K.conv_wgrad(x, grad_out, spec.taps, spec.fwd_ix)             # kernel layout
             if spec.param_kind == 0:
@@ -143,6 +163,14 @@ class _BNActFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, y, gamma, mean, rstd, scale, shift = ctx.saved_tensors
         gx, gres, gg, gb = K.bn_bwd(x, y, gy.contiguous(), gamma, mean, rstd, scale, shift, ctx.act, ctx.has_res)
+        if _DEBUG and ctx.act in (0, 1):
+            g = gy.double() * ((y > 0).double() if ctx.act == 1 else 1.0)
+            xh = (x.double() - mean.double()) * rstd.double()
+            n = x.shape[0]
+            ref = gamma.double() * rstd.double() * (g - g.sum(0) / n - xh * (g * xh).sum(0) / n)
+            _dbg_report(f"bn bwd C={x.shape[1]} rows={n} res={ctx.has_res}", gx.double(), ref)
+            if ctx.has_res:
+                _dbg_report("bn bwd residual grad", gres.double(), g)
         return gx, gg, gb, gres, None, None, None, None, None, None
 
 
@@ -220,3 +248,37 @@ def nchw_to_rows(x):
 def rows_to_nchw(rows, B, H, W):
     """(B*H*W, C) rows -> logical (B,C,H,W) tensor in channels-last memory (no copy)."""
     return rows.view(B, H, W, rows.shape[1]).permute(0, 3, 1, 2)
+
+
+class _DWConvFn(torch.autograd.Function):
+    """Depthwise KxK conv (padding K//2) on channels-last rows; weight is the nn.Conv2d parameter [C, 1, K, K]."""
+
+    @staticmethod
+    def forward(ctx, x_rows, weight, bias, B, H, W):
+        C, K = weight.shape[0], weight.shape[-1]
+        w_tc = weight.detach().reshape(C, K * K).t().contiguous()
+        out = K_.dwconv_fwd(x_rows, w_tc, bias.detach() if bias is not None else None, B, H, W, K)
+        ctx.geom = (B, H, W, K)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x_rows, w_tc)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        x_rows, w_tc = ctx.saved_tensors
+        B, H, W, K = ctx.geom
+        go = go.contiguous()
+        gx = K_.dwconv_fwd(go, w_tc, None, B, H, W, K, flip=True) if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            C = x_rows.shape[1]
+            gw = K_.dwconv_wgrad(x_rows, go, B, H, W, K).t().reshape(C, 1, K, K)
+        gb = K_.colsum(go) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb, None, None, None
+
+
+K_ = K
+
+
+def dwconv(x_rows, conv, B, H, W):
+    return _DWConvFn.apply(x_rows, conv.weight, conv.bias, B, H, W)

@@ -1,0 +1,106 @@
+// Depthwise KxK convolution (ConvNeXt `dwconv`, 7x7, padding 3, groups = C) on channels-last maps: forward, data gradient
+// and weight gradient.  Replaces cuDNN's depthwise conv in pcdet/ops/basicblock/modules/Basicblock_convn.py:13,47 (MIOpen
+// falls back to naive / batched-GEMM kernels for this shape: 16 ms of a 116 ms step before this file existed).
+// HBM/L2-bound: each lane owns 4 channels of one pixel (float4); the 49 neighbour rows are contiguous 1 KiB reads that hit
+// L2, weights are pre-transposed to [tap][C] so a wave reads them coalesced.
+#include "common.hpp"
+
+using namespace rd;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// out[p][c] = bias[c] + sum_t w[t][c] * in[p + off(t)][c];  FLIP reads tap (T-1-t) of w for tap t (data gradient).
+__global__ __launch_bounds__(256) void k_dwconv(const float *__restrict__ in, const float *__restrict__ wt /*[T][C]*/, const float *__restrict__ bias,
+                                                int B, int H, int W, int C, int K, int flip, float *__restrict__ out) {
+    const int c4n = C / 4;
+    const int64_t total = (int64_t)B * H * W * c4n;
+    const int pad = K / 2, T = K * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        const int64_t p = i / c4n;
+        const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
+        f32x4 acc = bias ? *reinterpret_cast<const f32x4 *>(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ky = 0; ky < K; ++ky) {
+            const int yy = y + ky - pad;
+            if (yy < 0 || yy >= H) continue;
+            for (int kx = 0; kx < K; ++kx) {
+                const int xx = x + kx - pad;
+                if (xx < 0 || xx >= W) continue;
+                const int t = ky * K + kx;
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(wt + (int64_t)(flip ? T - 1 - t : t) * C + c);
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(in + (((int64_t)b * H + yy) * W + xx) * C + c);
+                acc += wv * v;
+            }
+        }
+        *reinterpret_cast<f32x4 *>(out + p * C + c) = acc;
+    }
+}
+
+// dw[t][c] = sum_p go[p][c] * in[p + off(t)][c].  grid = (pixel chunks, T); block = 256 = 4 pixel lanes x 64 channel quads
+// (C <= 256 per pass; loops over channel groups for wider maps).  Per-block partial -> partial[chunk][t][c]; summed by
+// k_dw_wsum in fixed order.
+__global__ __launch_bounds__(256) void k_dwconv_wgrad(const float *__restrict__ in, const float *__restrict__ go, int B, int H, int W, int C, int K,
+                                                      int pix_per_chunk, float *__restrict__ partial) {
+    __shared__ float red[4][256];
+    const int t = blockIdx.y, ky = t / K, kx = t % K, pad = K / 2;
+    const int64_t n_pix = (int64_t)B * H * W;
+    const int64_t p0 = (int64_t)blockIdx.x * pix_per_chunk, p1 = min(n_pix, p0 + pix_per_chunk);
+    const int lane_c = (threadIdx.x & 63) * 4, sub = threadIdx.x >> 6;
+    for (int cg = 0; cg < C; cg += 256) {
+        const int c = cg + lane_c;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (c < C) {
+            for (int64_t p = p0 + sub; p < p1; p += 4) {
+                const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
+                const int yy = y + ky - pad, xx = x + kx - pad;
+                if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                const f32x4 g = *reinterpret_cast<const f32x4 *>(go + p * C + c);
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(in + (((int64_t)b * H + yy) * W + xx) * C + c);
+                acc += g * v;
+            }
+        }
+        *reinterpret_cast<f32x4 *>(&red[sub][lane_c]) = acc;
+        __syncthreads();
+        if (threadIdx.x < 256 && cg + (int)threadIdx.x < C) {
+            const int cc = threadIdx.x;
+            partial[((int64_t)blockIdx.x * gridDim.y + t) * C + cg + cc] = red[0][cc] + red[1][cc] + red[2][cc] + red[3][cc];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_dw_wsum(const float *__restrict__ partial, int n_chunks, int TC, float *__restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= TC) return;
+    double s = 0.0;
+    for (int k = 0; k < n_chunks; ++k) s += (double)partial[(int64_t)k * TC + i];
+    out[i] = (float)s;
+}
+
+extern "C" int rd_dwconv_fwd(const float *in, const float *weight_tc, const float *bias, int B, int H, int W, int C, int K, int flip, float *out,
+                             void *stream) {
+    RD_REQUIRE(C % 4 == 0 && K % 2 == 1 && K <= 11 && B > 0 && H > 0 && W > 0, "rd_dwconv_fwd: bad sizes");
+    int64_t total = (int64_t)B * H * W * (C / 4);
+    k_dwconv<<<(int)std::min<int64_t>(cdiv(total, 256), 8192), 256, 0, S(stream)>>>(in, weight_tc, bias, B, H, W, C, K, flip, out);
+    return check_launch("rd_dwconv_fwd");
+}
+
+extern "C" int64_t rd_dwconv_wgrad_ws_bytes(int B, int H, int W, int C, int K) {
+    int64_t n_pix = (int64_t)B * H * W;
+    int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(64, cdiv(n_pix, 64)));
+    return chunks * K * K * C * 4;
+}
+
+extern "C" int rd_dwconv_wgrad(const float *in, const float *grad_out, int B, int H, int W, int C, int K, float *grad_w_tc, float *ws,
+                               int64_t ws_bytes, void *stream) {
+    RD_REQUIRE(C % 4 == 0 && K % 2 == 1 && K <= 11, "rd_dwconv_wgrad: bad sizes");
+    int64_t n_pix = (int64_t)B * H * W;
+    int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(64, cdiv(n_pix, 64)));
+    RD_REQUIRE(ws_bytes >= chunks * K * K * C * 4, "rd_dwconv_wgrad: workspace too small");
+    int ppc = (int)cdiv(n_pix, chunks);
+    hipStream_t st = S(stream);
+    dim3 grid((unsigned)chunks, (unsigned)(K * K));
+    k_dwconv_wgrad<<<grid, 256, 0, st>>>(in, grad_out, B, H, W, C, K, ppc, ws);
+    k_dw_wsum<<<cdiv(K * K * C, 256), 256, 0, st>>>(ws, (int)chunks, K * K * C, grad_w_tc);
+    return check_launch("rd_dwconv_wgrad");
+}

@@ -9,7 +9,7 @@ using namespace rd;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int RED_MAX_BLOCKS = 512;
+constexpr int RED_MAX_BLOCKS = 256;
 
 __device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * (1.f + erff(z * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_grad(float z) {
@@ -48,12 +48,23 @@ __global__ __launch_bounds__(256) void k_colreduce(int64_t rows, int C, F f, flo
     }
 }
 
-__global__ void k_colreduce_final(const float *partial, int n_blocks, int C2, float *out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= C2) return;
+// Final stage: 32 columns per block; 8 row-groups of threads walk the per-block partials with coalesced 128-byte reads, sum in
+// double in a fixed order (deterministic), then combine through LDS.
+__global__ __launch_bounds__(256) void k_colreduce_final(const float *__restrict__ partial, int n_blocks, int C2, float *out) {
+    __shared__ double red[8][32];
+    const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + c;
     double s = 0.0;
-    for (int b = 0; b < n_blocks; ++b) s += (double)partial[(int64_t)b * C2 + i];
-    out[i] = (float)s;
+    if (col < C2)
+        for (int b = r; b < n_blocks; b += 8) s += (double)partial[(int64_t)b * C2 + col];
+    red[r][c] = s;
+    __syncthreads();
+    if (r == 0 && col < C2) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][c];
+        out[col] = (float)t;
+    }
 }
 
 template <class F>
@@ -65,7 +76,7 @@ static int colreduce(int64_t rows, int C, F f, float *out2C, float *ws, int64_t 
                (long long)blocks * 2 * C * 4);
     size_t shm = (size_t)groups * 2 * C * 4;
     k_colreduce<F><<<blocks, 256, shm, st>>>(rows, C, f, ws);
-    k_colreduce_final<<<cdiv(2 * C, 256), 256, 0, st>>>(ws, blocks, 2 * C, out2C);
+    k_colreduce_final<<<cdiv(2 * C, 32), 256, 0, st>>>(ws, blocks, 2 * C, out2C);
     return check_launch(who);
 }
 

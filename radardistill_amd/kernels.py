@@ -175,7 +175,7 @@ def conv_fwd(x, weight_k, taps, bias, out_rows, Cout, ix, scale=None, shift=None
     if residual is not None and (_chk(residual, f32, "residual").shape != (out_rows, Cout)):
         raise RuntimeError("conv residual shape mismatch")
     out = torch.empty((out_rows, Cout), dtype=f32, device=x.device)
-    prof = CONV_PROFILE is not None and Cout > 64 and ix.mode in (1, 2)      # the BN=128 dense-geometry instantiation
+    prof = CONV_PROFILE is not None and Cout > 64 and ix.mode != 3      # every launch of the k_conv_igemm<128,2,2,false> instantiation
     if prof:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -183,7 +183,16 @@ def conv_fwd(x, weight_k, taps, bias, out_rows, Cout, ix, scale=None, shift=None
                                    _p(scale), _p(shift), _p(residual), int(relu), _p(stats), _stream()), "rd_conv_fwd")
     if prof:
         e1.record()
-        CONV_PROFILE.append((e0, e1, 2.0 * out_rows * taps * Cin * Cout))
+        # algorithmic flops: dense 2*k^2*Cin*Cout*rows_out; sparse 2*pairs*Cin*Cout (pairs = valid table entries,
+        # counted once per table on the device and read after the timed region)
+        if ix.mode == 0:
+            pairs = getattr(nbr_keepalive, "_rd_pairs", None) if nbr_keepalive is not None else None
+            if pairs is None and nbr_keepalive is not None:
+                pairs = (nbr_keepalive >= 0).sum()
+                nbr_keepalive._rd_pairs = pairs
+            CONV_PROFILE.append((e0, e1, pairs, 2.0 * Cin * Cout, (in_rows, Cin, Cout, taps, ix.mode)))
+        else:
+            CONV_PROFILE.append((e0, e1, None, 2.0 * out_rows * taps * Cin * Cout, (in_rows, Cin, Cout, taps, ix.mode)))
     return out
 
 
@@ -387,3 +396,26 @@ def boxes_aligned_overlap_bev(boxes_a, boxes_b):
     out = torch.zeros((n, 1), dtype=f32, device=boxes_a.device)
     check(native.lib().rd_boxes_aligned_overlap_bev(n, _p(boxes_a), _p(boxes_b), _p(out), _stream()), "rd_boxes_aligned_overlap_bev")
     return out
+
+
+# ------------------------------------------------------------------------------------------ depthwise conv
+def dwconv_fwd(x_rows, w_tc, bias, B, H, W, K, flip=False):
+    _chk(x_rows, f32, "dwconv input", 2); _chk(w_tc, f32, "dwconv weight", 2)
+    C = x_rows.shape[1]
+    if x_rows.shape[0] != B * H * W or w_tc.shape != (K * K, C):
+        raise RuntimeError("dwconv_fwd: shape mismatch")
+    out = torch.empty_like(x_rows)
+    check(native.lib().rd_dwconv_fwd(_p(x_rows), _p(w_tc), _p(bias), B, H, W, C, K, int(flip), _p(out), _stream()), "rd_dwconv_fwd")
+    return out
+
+
+def dwconv_wgrad(x_rows, go_rows, B, H, W, K):
+    _chk(x_rows, f32, "dwconv input", 2); _chk(go_rows, f32, "dwconv grad", 2)
+    C = x_rows.shape[1]
+    if x_rows.shape != go_rows.shape or x_rows.shape[0] != B * H * W:
+        raise RuntimeError("dwconv_wgrad: shape mismatch")
+    nb = native.lib().rd_dwconv_wgrad_ws_bytes(B, H, W, C, K)
+    ws = torch.empty(nb // 4, dtype=f32, device=x_rows.device)
+    gw = torch.empty((K * K, C), dtype=f32, device=x_rows.device)
+    check(native.lib().rd_dwconv_wgrad(_p(x_rows), _p(go_rows), B, H, W, C, K, _p(gw), _p(ws), nb, _stream()), "rd_dwconv_wgrad")
+    return gw

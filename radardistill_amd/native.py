@@ -64,6 +64,9 @@ SIGNATURES = {
     "rd_opt_chunk_elems": (c_int, []),
     "rd_grad_norm": (c_int, [_P, _P, c_int, c_f32, _P, _P, c_i64, _P]),
     "rd_adam_step": (c_int, [_P, _P, c_int, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, _P, _P]),
+    "rd_dwconv_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "rd_dwconv_wgrad_ws_bytes": (c_i64, [c_int, c_int, c_int, c_int, c_int]),
+    "rd_dwconv_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_i64, _P]),
 }
 
 

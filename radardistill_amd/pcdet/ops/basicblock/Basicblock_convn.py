@@ -72,12 +72,8 @@ class ConvNeXtBlock(nn.Module):
             rows, H, W = self.down_layer.forward_rows(rows, B, H, W, om, True)
         C = rows.shape[1]
         identity = rows
-        xm = A.rows_to_nchw(rows, B, H, W)
-        y = F.conv2d(xm, self.dwconv.weight, self.dwconv.bias, padding=3, groups=C)          # depthwise 7x7 (channels-last)
-        y = y.permute(0, 2, 3, 1)
-        if not y.is_contiguous():
-            y = y.contiguous()
-        y = self.norm(y)
+        y = A.dwconv(rows, self.dwconv, B, H, W)                                             # depthwise 7x7 (dwconv.hip)
+        y = self.norm(y.view(B, H, W, C))
         y = D.linear_rows(y.reshape(-1, C), self.pwconv1)
         y = self.act(y)
         y = self.grn(y.view(B, H, W, 4 * C))

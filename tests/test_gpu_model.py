@@ -292,12 +292,11 @@ def test_full_distillation_step_vs_oracle():
         assert a is not None, k
         if b is None:
             b = torch.zeros_like(state[k])
-        denom = float(b.abs().max())
-        err = float((a.detach().cpu() - b).abs().max())
-        rel = err / (denom + 1e-4 * gscale)
-        if rel > worst[1]:
-            worst = (k, rel)
-        # see tests/test_gpu_kernels.py::test_sparse_enc_c2_vs_oracle for why gradients get 1e-2 + a global-scale floor
-        assert err <= 1e-2 * denom + 1e-4 * gscale, (k, err, denom, gscale)
-    print("worst relative gradient error", worst)
+        # relative L2 per tensor (ReLU sign flips of ~1e-8 pre-activations: see tests/test_gpu_kernels.py::test_sparse_enc_c2_vs_oracle)
+        err = float((a.detach().cpu() - b).norm())
+        bound = 1e-2 * float(b.norm()) + 1e-4 * gscale * (b.numel() ** 0.5)
+        if err / bound > worst[1]:
+            worst = (k, err / bound)
+        assert err <= bound, (k, err, float(b.norm()), gscale)
+    print("worst gradient error / bound", worst)
     assert int(model.global_step) == 1
