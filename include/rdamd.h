@@ -241,6 +241,26 @@ int64_t rd_dwconv_wgrad_ws_bytes(int B, int H, int W, int C, int K);
 int rd_dwconv_wgrad(const float *in, const float *grad_out, int B, int H, int W, int C, int K, float *grad_w_tc, float *ws, int64_t ws_bytes,
                     void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * K. CenterHead target assignment.  Replaces the host loops of Radar_CenterHead.assign_targets /
+ *    assign_target_of_single_head (pcdet/models/dense_heads/radar_center_head.py:128-252) and draw_gaussian_to_heatmap
+ *    (pcdet/models/model_utils/centernet_utils.py:38-69).  gt_boxes (B, M, box_dim) with the 1-based global class id in the
+ *    last column (0 = padding).  Outputs (zeroed inside): heatmaps (B, n_channels, fy, fx) with the heads' classes
+ *    concatenated on the channel axis; target_boxes (n_heads, B, max_objs, box_dim); inds / masks (n_heads, B, max_objs) int64;
+ *    gt_box (n_heads, B, max_objs, 7).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int n_classes, n_heads, n_channels;
+    int head_of_class[16];   /* global class id (1-based) -> head */
+    int local_of_class[16];  /* global class id -> 0-based class index inside its head */
+    int chan_off[8];         /* first heat-map channel of each head */
+    float pcr0, pcr1, vs0, vs1;
+    int stride, fx, fy, max_objs, min_radius;
+    float overlap;
+} rd_target_cfg;
+int rd_center_targets(const float *gt_boxes, int B, int M, int box_dim, const rd_target_cfg *cfg, float *heatmaps, float *target_boxes,
+                      int64_t *inds, int64_t *masks, float *gt_box, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,56 @@ def bump_weights_epoch():
     _WEIGHTS_EPOCH[0] += 1
 
 
+class _ZeroArena:
+    """Per-step pool of zero-initialised fp32 scratch (BatchNorm statistics, weight-gradient accumulators): ONE memset per
+    step instead of one torch.zeros launch per layer.  `begin_step()` re-zeroes and rewinds; slices stay valid until the next
+    begin_step() (all consumers finish inside the step they were handed out in, on the same stream)."""
+
+    def __init__(self):
+        self.buf = None
+        self.off = 0
+        self.high = 0
+
+    def begin_step(self, device):
+        need = max(self.high, 1 << 20)
+        if self.buf is None or self.buf.device != device or self.buf.numel() < need:
+            self.buf = torch.zeros(int(need * 1.25), dtype=torch.float32, device=device)
+        else:
+            self.buf[:max(self.off, 1)].zero_()
+        self.off = 0
+
+    def take(self, n, device):
+        n_al = (n + 63) // 64 * 64
+        if self.buf is None or self.buf.device != device or self.off + n_al > self.buf.numel():
+            self.high = max(self.high, self.off + n_al)          # grow on the next step; this request falls back to a fresh tensor
+            self.off += n_al
+            return torch.zeros(n, dtype=torch.float32, device=device)
+        out = self.buf[self.off:self.off + n]
+        self.off += n_al
+        self.high = max(self.high, self.off)
+        return out
+
+
+ARENA = _ZeroArena()
+_BN_TOUCHED = []          # BatchNorm modules that ran in train mode this step (num_batches_tracked bumped once, together)
+
+
+def begin_step(device):
+    ARENA.begin_step(device)
+    _BN_TOUCHED.clear()
+
+
+def end_forward():
+    """num_batches_tracked += 1 for every train-mode BatchNorm of this forward in one multi-tensor launch."""
+    if _BN_TOUCHED:
+        torch._foreach_add_([m.num_batches_tracked for m in _BN_TOUCHED], 1)
+        _BN_TOUCHED.clear()
+
+
+def zeros_stats(n, device):
+    return ARENA.take(n, device)
+
+
 def kernel_weight(param, Cout, Cin, taps, kind, flip=False):
     """Parameter -> kernel layout [Cout][taps][Cin] (or its data-gradient transpose), cached per parameter version."""
     key = (id(param), kind, flip)
@@ -178,16 +228,27 @@ def bn_act_train(x, bn, residual=None, act=1, stats=None):
     """bn: nn.BatchNorm1d/2d module (train mode semantics: batch stats, running-stat update)."""
     if x.shape[0] <= 1:
         raise ValueError("Expected more than 1 value per channel when training")     # torch's own train-mode BN error
-    bn.num_batches_tracked += 1
+    _BN_TOUCHED.append(bn)
     return _BNActFn.apply(x, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, float(bn.eps), float(bn.momentum), act, stats)
 
 
+_BN_FOLD_CACHE = {}
+
+
 def bn_eval_scale_shift(bn):
-    """Folded eval-mode BatchNorm: y = x*scale + shift."""
-    rstd = torch.rsqrt(bn.running_var + bn.eps)
-    scale = bn.weight * rstd
-    shift = bn.bias - bn.running_mean * scale
-    return scale.detach().contiguous(), shift.detach().contiguous()
+    """Folded eval-mode BatchNorm: y = x*scale + shift.  Cached per module while its parameters / running statistics are
+    unchanged (the frozen teacher: computed once instead of 4 small launches per layer per step)."""
+    ver = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, _WEIGHTS_EPOCH[0] if bn.weight.requires_grad else -1,
+           bn.weight.data_ptr(), bn.running_var.data_ptr())
+    hit = _BN_FOLD_CACHE.get(id(bn))
+    if hit is not None and hit[0] == ver:
+        return hit[1], hit[2]
+    with torch.no_grad():
+        rstd = torch.rsqrt(bn.running_var + bn.eps)
+        scale = (bn.weight * rstd).contiguous()
+        shift = (bn.bias - bn.running_mean * scale).contiguous()
+    _BN_FOLD_CACHE[id(bn)] = (ver, scale, shift)
+    return scale, shift
 
 
 class _BNEvalActFn(torch.autograd.Function):

@@ -19,7 +19,6 @@ using namespace rd;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128;
 constexpr int KB = 32;
 constexpr int LDK = KB + 4;  // padded LDS row (floats)
 constexpr int MAX_TAPS = 16;
@@ -67,12 +66,13 @@ __device__ __forceinline__ int src_row(const ConvArgs &a, int j, int t) {
     return (b * ix.Hin + iy) * ix.Win + ixx;
 }
 
-template <int BN, int WAVES_M, int WAVES_N, bool DEFORM>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool DEFORM>
 __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int MI = WM / 32, NI = WN / 32;
     constexpr int BP = BN / 32;  // B float4 loads per thread
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+    constexpr int AP = BM / 32;  // A float4 loads per thread
+    static_assert(WAVES_M * WAVES_N == 4 && MI >= 1 && NI >= 1, "4 waves, each at least one 32x32 MFMA tile");
     __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDK];
     __shared__ int s_tapmask;
     constexpr int BUF = (BM + BN) * LDK;  // floats per buffer: [A tile 128 x 36][B tile BN x 36]
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
     __syncthreads();
     {
         int mask = 0;
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < AP; ++p) {
             int j = m0 + ld_r + 32 * p;
             if ((tid & 7) == 0)
                 for (int t = 0; t < a.taps; ++t)
@@ -109,10 +109,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[4], rb[BP];
-    int rows[4];
-    int4 sidx[DEFORM ? 4 : 1];
-    f32x4 sw[DEFORM ? 4 : 1];
+    f32x4 ra[AP], rb[BP];
+    int rows[AP];
+    int4 sidx[DEFORM ? AP : 1];
+    f32x4 sw[DEFORM ? AP : 1];
     int cur_tap = -1, tap_iter_mask = tapmask;
 
     auto load_tile = [&](int s) {
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
             tap_iter_mask &= tap_iter_mask - 1;
             if constexpr (DEFORM) {
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
+                for (int p = 0; p < AP; ++p) {
                     const int j = m0 + ld_r + 32 * p;
                     if (j < a.out_rows) {
                         const int64_t o = ((int64_t)j * a.taps + cur_tap) * 4;
@@ -134,11 +134,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
                 }
             } else {
 #pragma unroll
-                for (int p = 0; p < 4; ++p) rows[p] = src_row(a, m0 + ld_r + 32 * p, cur_tap);
+                for (int p = 0; p < AP; ++p) rows[p] = src_row(a, m0 + ld_r + 32 * p, cur_tap);
             }
         }
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < AP; ++p) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if constexpr (DEFORM) {
                 // A element = mask * bilinear(x): up to four weighted rows (weights already hold mask * corner weight)
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(lds + buf * BUF + (ld_r + 32 * p) * LDK + ld_c) = ra[p];
+        for (int p = 0; p < AP; ++p) *reinterpret_cast<f32x4 *>(lds + buf * BUF + (ld_r + 32 * p) * LDK + ld_c) = ra[p];
 #pragma unroll
         for (int p = 0; p < BP; ++p) *reinterpret_cast<f32x4 *>(lds + buf * BUF + BM * LDK + (ld_r + 32 * p) * LDK + ld_c) = rb[p];
     };
@@ -274,18 +274,36 @@ extern "C" int rd_conv_fwd(const float *in, int in_rows, int Cin, const float *w
     ConvArgs a{in, in_rows, Cin, weight_k, taps, bias, out, out_rows, Cout, *idx, scale, shift, residual, relu, stats};
     hipStream_t st = S(stream);
     dim3 block(256);
+    // Tile choice: 128x128 when that already gives every CU two workgroups (512 resident blocks), otherwise 64x64 tiles
+    // (4x the workgroups; operands are L2-resident at these sizes, so the extra re-reads stay on chip).
+    const int64_t big_blocks = cdiv(out_rows, 128) * cdiv(Cout, 128);
     if (idx->mode == 3) {
-        dim3 grid((unsigned)cdiv(out_rows, BM), (unsigned)cdiv(Cout, 128));
-        k_conv_igemm<128, 2, 2, true><<<grid, block, 0, st>>>(a);
+        if (big_blocks >= 384) {
+            dim3 grid((unsigned)cdiv(out_rows, 128), (unsigned)cdiv(Cout, 128));
+            k_conv_igemm<128, 128, 2, 2, true><<<grid, block, 0, st>>>(a);
+        } else {
+            dim3 grid((unsigned)cdiv(out_rows, 64), (unsigned)cdiv(Cout, 64));
+            k_conv_igemm<64, 64, 2, 2, true><<<grid, block, 0, st>>>(a);
+        }
     } else if (Cout > 64) {
-        dim3 grid((unsigned)cdiv(out_rows, BM), (unsigned)cdiv(Cout, 128));
-        k_conv_igemm<128, 2, 2, false><<<grid, block, 0, st>>>(a);
+        if (big_blocks >= 384) {
+            dim3 grid((unsigned)cdiv(out_rows, 128), (unsigned)cdiv(Cout, 128));
+            k_conv_igemm<128, 128, 2, 2, false><<<grid, block, 0, st>>>(a);
+        } else {
+            dim3 grid((unsigned)cdiv(out_rows, 64), (unsigned)cdiv(Cout, 64));
+            k_conv_igemm<64, 64, 2, 2, false><<<grid, block, 0, st>>>(a);
+        }
     } else if (Cout > 32) {
-        dim3 grid((unsigned)cdiv(out_rows, BM), 1);
-        k_conv_igemm<64, 2, 2, false><<<grid, block, 0, st>>>(a);
+        if (cdiv(out_rows, 128) >= 384) {
+            dim3 grid((unsigned)cdiv(out_rows, 128), 1);
+            k_conv_igemm<128, 64, 2, 2, false><<<grid, block, 0, st>>>(a);
+        } else {
+            dim3 grid((unsigned)cdiv(out_rows, 64), 1);
+            k_conv_igemm<64, 64, 2, 2, false><<<grid, block, 0, st>>>(a);
+        }
     } else {
-        dim3 grid((unsigned)cdiv(out_rows, BM), 1);
-        k_conv_igemm<32, 4, 1, false><<<grid, block, 0, st>>>(a);
+        dim3 grid((unsigned)cdiv(out_rows, 128), 1);
+        k_conv_igemm<128, 32, 4, 1, false><<<grid, block, 0, st>>>(a);
     }
     return check_launch("rd_conv_fwd");
 }

@@ -175,7 +175,9 @@ def conv_fwd(x, weight_k, taps, bias, out_rows, Cout, ix, scale=None, shift=None
     if residual is not None and (_chk(residual, f32, "residual").shape != (out_rows, Cout)):
         raise RuntimeError("conv residual shape mismatch")
     out = torch.empty((out_rows, Cout), dtype=f32, device=x.device)
-    prof = CONV_PROFILE is not None and Cout > 64 and ix.mode != 3      # every launch of the k_conv_igemm<128,2,2,false> instantiation
+    # every launch of the Cout > 64, non-deform instantiations; `tile` mirrors the selection rule of rd_conv_fwd (conv.hip)
+    prof = CONV_PROFILE is not None and Cout > 64 and ix.mode != 3
+    tile = 128 if ((out_rows + 127) // 128) * ((Cout + 127) // 128) >= 384 else 64
     if prof:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -190,9 +192,9 @@ def conv_fwd(x, weight_k, taps, bias, out_rows, Cout, ix, scale=None, shift=None
             if pairs is None and nbr_keepalive is not None:
                 pairs = (nbr_keepalive >= 0).sum()
                 nbr_keepalive._rd_pairs = pairs
-            CONV_PROFILE.append((e0, e1, pairs, 2.0 * Cin * Cout, (in_rows, Cin, Cout, taps, ix.mode)))
+            CONV_PROFILE.append((e0, e1, pairs, 2.0 * Cin * Cout, (in_rows, Cin, Cout, taps, ix.mode, tile)))
         else:
-            CONV_PROFILE.append((e0, e1, None, 2.0 * out_rows * taps * Cin * Cout, (in_rows, Cin, Cout, taps, ix.mode)))
+            CONV_PROFILE.append((e0, e1, None, 2.0 * out_rows * taps * Cin * Cout, (in_rows, Cin, Cout, taps, ix.mode, tile)))
     return out
 
 
@@ -202,7 +204,8 @@ def conv_wgrad(x, grad_out, taps, ix):
     _chk(grad_out, f32, "wgrad grad_out", 2)
     in_rows, Cin = x.shape
     out_rows, Cout = grad_out.shape
-    gw = torch.zeros((Cout, taps, Cin), dtype=f32, device=x.device)
+    from . import autograd as _A
+    gw = _A.ARENA.take(Cout * taps * Cin, x.device).view(Cout, taps, Cin)          # zero-initialised accumulator (atomics)
     check(native.lib().rd_conv_wgrad(_p(x), in_rows, Cin, _p(grad_out), out_rows, Cout, taps, ctypes.byref(ix), _p(gw), _stream()), "rd_conv_wgrad")
     return gw
 
@@ -419,3 +422,20 @@ def dwconv_wgrad(x_rows, go_rows, B, H, W, K):
     gw = torch.empty((K * K, C), dtype=f32, device=x_rows.device)
     check(native.lib().rd_dwconv_wgrad(_p(x_rows), _p(go_rows), B, H, W, C, K, _p(gw), _p(ws), nb, _stream()), "rd_dwconv_wgrad")
     return gw
+
+
+# ------------------------------------------------------------------------------------------ CenterHead targets
+def center_targets(gt_boxes, cfg_struct):
+    """gt_boxes (B, M, D) CUDA fp32 -> stacked targets dict (see rd_center_targets)."""
+    _chk(gt_boxes, f32, "gt_boxes", 3)
+    B, M, D = gt_boxes.shape
+    c = cfg_struct
+    dev = gt_boxes.device
+    hm = torch.empty((B, c.n_channels, c.fy, c.fx), dtype=f32, device=dev)
+    tb = torch.empty((c.n_heads, B, c.max_objs, D), dtype=f32, device=dev)
+    inds = torch.empty((c.n_heads, B, c.max_objs), dtype=torch.int64, device=dev)
+    masks = torch.empty((c.n_heads, B, c.max_objs), dtype=torch.int64, device=dev)
+    gb = torch.empty((c.n_heads, B, c.max_objs, 7), dtype=f32, device=dev)
+    check(native.lib().rd_center_targets(_p(gt_boxes), B, M, D, ctypes.byref(c), _p(hm), _p(tb), _p(inds), _p(masks), _p(gb), _stream()),
+          "rd_center_targets")
+    return {"heatmaps": hm, "target_boxes": tb, "inds": inds, "masks": masks, "gt_box": gb}

@@ -24,6 +24,14 @@ class ConvIndex(ctypes.Structure):
                 ("samp_idx", c_vp), ("samp_w", c_vp)]
 
 
+class TargetCfg(ctypes.Structure):
+    """rd_target_cfg of include/rdamd.h."""
+    _fields_ = [("n_classes", c_int), ("n_heads", c_int), ("n_channels", c_int), ("head_of_class", c_int * 16),
+                ("local_of_class", c_int * 16), ("chan_off", c_int * 8), ("pcr0", c_f32), ("pcr1", c_f32), ("vs0", c_f32),
+                ("vs1", c_f32), ("stride", c_int), ("fx", c_int), ("fy", c_int), ("max_objs", c_int), ("min_radius", c_int),
+                ("overlap", c_f32)]
+
+
 # name -> (restype, argtypes).  Must list EVERY symbol declared in include/rdamd.h (tests check this).
 _P = c_vp
 SIGNATURES = {
@@ -67,6 +75,7 @@ SIGNATURES = {
     "rd_dwconv_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "rd_dwconv_wgrad_ws_bytes": (c_i64, [c_int, c_int, c_int, c_int, c_int]),
     "rd_dwconv_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_i64, _P]),
+    "rd_center_targets": (c_int, [_P, c_int, c_int, c_int, ctypes.POINTER(TargetCfg), _P, _P, _P, _P, _P, _P]),
 }
 
 

@@ -32,7 +32,7 @@ class _SparseConvBNReLU(spconv.SparseSequential):
             scale, shift = A.bn_eval_scale_shift(bn)
             feats = A.conv_inference(x.features, conv.weight, conv.bias, spec, conv.out_channels, scale, shift, None, True)
         elif bn.training:
-            stats = torch.zeros(2 * conv.out_channels, dtype=torch.float32, device=x.features.device)
+            stats = A.zeros_stats(2 * conv.out_channels, x.features.device)
             raw = A.conv(x.features, conv.weight, conv.bias, spec, conv.out_channels, stats)
             feats = A.bn_act_train(raw, bn, None, act=1, stats=stats)
         else:
@@ -99,10 +99,10 @@ class SparseBasicBlock(spconv.SparseModule):
             y = A.conv_inference(f, self.conv1.weight, self.conv1.bias, spec, C, s1, h1, None, True)
             y = A.conv_inference(y, self.conv2.weight, self.conv2.bias, spec, C, s2, h2, f, True)
         elif self.bn1.training:
-            st1 = torch.zeros(2 * C, dtype=torch.float32, device=f.device)
+            st1 = A.zeros_stats(2 * C, f.device)
             y = A.conv(f, self.conv1.weight, self.conv1.bias, spec, C, st1)
             y = A.bn_act_train(y, self.bn1, None, act=1, stats=st1)
-            st2 = torch.zeros(2 * C, dtype=torch.float32, device=f.device)
+            st2 = A.zeros_stats(2 * C, f.device)
             y = A.conv(y, self.conv2.weight, self.conv2.bias, spec, C, st2)
             y = A.bn_act_train(y, self.bn2, f, act=1, stats=st2)
         else:
@@ -173,12 +173,27 @@ class PillarRes18BackBone8x(nn.Module):
         self.num_point_features = 256
         self.backbone_channels = {'x_conv1': 32, 'x_conv2': 64, 'x_conv3': 128, 'x_conv4': 256, 'x_conv5': 256}
 
+    def prepare(self, batch_dict):
+        """Build the input SparseConvTensor and the whole 4-level active-site pyramid (rank grids + neighbour tables) before any
+        convolution is enqueued (3 small device->host count reads per branch)."""
+        p = self.IN_PREFIX
+        if p + 'pillar_features' not in batch_dict:
+            return
+        x = SparseConvTensor(features=batch_dict[p + 'pillar_features'], indices=batch_dict[p + 'pillar_coords'].int(),
+                             spatial_shape=self.sparse_shape, batch_size=batch_dict['batch_size'])
+        lvl = x._level
+        lvl.subm_spec()
+        for _ in range(3):
+            lvl, _ = lvl.down()
+            lvl.subm_spec()
+        batch_dict[p + '_sparse_input'] = x
+
     def forward(self, batch_dict):
         p = self.IN_PREFIX
-        pillar_features, pillar_coords = batch_dict[p + 'pillar_features'], batch_dict[p + 'pillar_coords']
-        batch_size = batch_dict['batch_size']
-        x = SparseConvTensor(features=pillar_features, indices=pillar_coords.int(), spatial_shape=self.sparse_shape,
-                             batch_size=batch_size)
+        x = batch_dict.pop(p + '_sparse_input', None)
+        if x is None:
+            self.prepare(batch_dict)
+            x = batch_dict.pop(p + '_sparse_input')
         x_conv1 = self.conv1(x)
         x_conv2 = self.conv2(x_conv1)
         x_conv3 = self.conv3(x_conv2)

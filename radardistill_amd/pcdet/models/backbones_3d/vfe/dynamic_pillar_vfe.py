@@ -9,6 +9,7 @@ Linear -> BatchNorm -> ReLU -> per-pillar max kernel (two passes in training, fo
 import torch
 import torch.nn as nn
 
+from radardistill_amd import autograd as A
 from radardistill_amd import kernels as K
 from radardistill_amd import sparse as SP
 from .vfe_template import VFETemplate
@@ -105,7 +106,7 @@ class DynamicPillarVFESimple2D(VFETemplate):
             stats = K.vfe_linear_stats(points, point_row, coords, acc, w.detach().contiguous(), g)
             if n_valid <= 1:
                 raise ValueError("Expected more than 1 value per channel when training")
-            bn.num_batches_tracked += 1
+            A._BN_TOUCHED.append(bn)
             mean, rstd, scale, shift = K.bn_finalize(stats, n_valid, 32, bn.weight.detach(), bn.bias.detach(), float(bn.eps),
                                                      float(bn.momentum), bn.running_mean, bn.running_var)
             if torch.is_grad_enabled() and w.requires_grad:

@@ -157,6 +157,40 @@ class Radar_CenterHead(nn.Module):
         gt_box[:n, :7] = torch.where(okf[:, None], gt_boxes[:n, :7], gt_box[:n, :7])
         return heatmap, ret_boxes, inds, mask, gt_box
 
+    def _target_cfg(self, feature_map_size_xy):
+        from radardistill_amd.native import TargetCfg
+        cfg = self.model_cfg.TARGET_ASSIGNER_CONFIG
+        c = TargetCfg()
+        c.n_classes, c.n_heads = len(self.class_names), len(self.class_names_each_head)
+        c.n_channels = sum(len(x) for x in self.class_names_each_head)
+        off = 0
+        for h, names in enumerate(self.class_names_each_head):
+            c.chan_off[h] = off
+            off += len(names)
+            for l, n in enumerate(names):
+                g = self.class_names.index(n) + 1
+                c.head_of_class[g], c.local_of_class[g] = h, l
+        c.pcr0, c.pcr1 = float(self.point_cloud_range[0]), float(self.point_cloud_range[1])
+        c.vs0, c.vs1 = float(self.voxel_size[0]), float(self.voxel_size[1])
+        c.stride, c.fx, c.fy = int(cfg.FEATURE_MAP_STRIDE), int(feature_map_size_xy[0]), int(feature_map_size_xy[1])
+        c.max_objs, c.min_radius, c.overlap = int(cfg.NUM_MAX_OBJS), int(cfg.MIN_RADIUS), float(cfg.GAUSSIAN_OVERLAP)
+        return c
+
+    def assign_targets_gpu(self, gt_boxes, feature_map_size):
+        """Same targets as assign_targets, produced by ONE HIP kernel from the device copy of gt_boxes (targets.hip)."""
+        from radardistill_amd import kernels as K
+        fm = list(feature_map_size)[::-1]
+        stk = K.center_targets(gt_boxes.float().contiguous(), self._target_cfg(fm))
+        ret_dict = {'heatmaps': [], 'target_boxes': [], 'inds': [], 'masks': [], 'heatmap_masks': [], 'gt_box': []}
+        c0 = 0
+        for h, names in enumerate(self.class_names_each_head):
+            ret_dict['heatmaps'].append(stk['heatmaps'][:, c0:c0 + len(names)])
+            c0 += len(names)
+            ret_dict['target_boxes'].append(stk['target_boxes'][h]); ret_dict['inds'].append(stk['inds'][h])
+            ret_dict['masks'].append(stk['masks'][h]); ret_dict['gt_box'].append(stk['gt_box'][h])
+        ret_dict['_stacked'] = stk
+        return ret_dict
+
     def assign_targets(self, gt_boxes, feature_map_size=None, **kwargs):
         """gt_boxes (B, M, 10).  Computed on the host like the reference (radar_center_head.py:189-252) but from a host copy
         of the boxes when the caller provides one (`gt_boxes_host`), so no device->host sync is needed; the result is
@@ -167,9 +201,9 @@ class Radar_CenterHead(nn.Module):
         dev = gt_boxes.device
         gt_cpu = torch.as_tensor(host).float().clone() if host is not None else gt_boxes.detach().cpu().clone()
         batch_size = gt_cpu.shape[0]
-        ret_dict = {'heatmaps': [], 'target_boxes': [], 'inds': [], 'masks': [], 'heatmap_masks': [], 'gt_box': []}
         cls_all = gt_cpu[:, :, -1].long()
         name_to_global = {n: i + 1 for i, n in enumerate(self.class_names)}
+        per_head = []
         for cur_class_names in self.class_names_each_head:
             ids = torch.tensor([name_to_global[n] for n in cur_class_names])
             lists = [[], [], [], [], []]
@@ -186,8 +220,21 @@ class Radar_CenterHead(nn.Module):
                     gaussian_overlap=cfg.GAUSSIAN_OVERLAP, min_radius=cfg.MIN_RADIUS)
                 for l, o in zip(lists, out):
                     l.append(o)
-            for key, l in zip(('heatmaps', 'target_boxes', 'inds', 'masks', 'gt_box'), lists):
-                ret_dict[key].append(torch.stack(l, dim=0).to(dev, non_blocking=True))
+            per_head.append([torch.stack(l, dim=0) for l in lists])
+        # one upload per quantity: heat-maps concatenated over heads on the channel axis, the slot tensors stacked over heads
+        hm_all = torch.cat([ph[0] for ph in per_head], dim=1).to(dev, non_blocking=True)
+        tb_all = torch.stack([ph[1] for ph in per_head], dim=0).to(dev, non_blocking=True)
+        ind_all = torch.stack([ph[2] for ph in per_head], dim=0).to(dev, non_blocking=True)
+        mask_all = torch.stack([ph[3] for ph in per_head], dim=0).to(dev, non_blocking=True)
+        gb_all = torch.stack([ph[4] for ph in per_head], dim=0).to(dev, non_blocking=True)
+        ret_dict = {'heatmaps': [], 'target_boxes': [], 'inds': [], 'masks': [], 'heatmap_masks': [], 'gt_box': []}
+        c0 = 0
+        for h, cur_class_names in enumerate(self.class_names_each_head):
+            ret_dict['heatmaps'].append(hm_all[:, c0:c0 + len(cur_class_names)])
+            c0 += len(cur_class_names)
+            ret_dict['target_boxes'].append(tb_all[h]); ret_dict['inds'].append(ind_all[h])
+            ret_dict['masks'].append(mask_all[h]); ret_dict['gt_box'].append(gb_all[h])
+        ret_dict['_stacked'] = {'heatmaps': hm_all, 'target_boxes': tb_all, 'inds': ind_all, 'masks': mask_all, 'gt_box': gb_all}
         return ret_dict
 
     def sigmoid(self, x):
@@ -195,6 +242,79 @@ class Radar_CenterHead(nn.Module):
 
     # ------------------------------------------------------------------ loss
     def get_loss(self):
+        """All task heads in ONE batched pass (same per-head values and tb_dict entries as the reference's per-head loop,
+        radar_center_head.py:258-330): heat-map channels concatenated, regression maps stacked over heads."""
+        pred_dicts = self.forward_ret_dict['pred_dicts']
+        target_dicts = self.forward_ret_dict['target_dicts']
+        if '_stacked' not in target_dicts or not (self.with_iou and self.with_iou_reg):
+            return self.get_loss_per_head()
+        st = target_dicts['_stacked']
+        lw = self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS
+        nh = len(pred_dicts)
+        dev = st['heatmaps'].device
+        tb_dict = {}
+        # ---- focal loss on all heat-map channels at once; per-head normalisation by that head's positives
+        nc = [p['hm'].shape[1] for p in pred_dicts]
+        head_of_ch = torch.repeat_interleave(torch.arange(nh), torch.tensor(nc)).to(dev)
+        hm = self.sigmoid(torch.cat([p['hm'] for p in pred_dicts], dim=1))
+        gt = st['heatmaps']
+        pos_inds = gt.eq(1).float()
+        neg_inds = gt.lt(1).float()
+        pos_loss = (torch.log(hm) * torch.pow(1 - hm, 2) * pos_inds).sum((0, 2, 3))
+        neg_loss = (torch.log(1 - hm) * torch.pow(hm, 2) * torch.pow(1 - gt, 4) * neg_inds).sum((0, 2, 3))
+        per_ch = torch.stack([pos_loss + neg_loss, pos_inds.sum((0, 2, 3))], dim=0)                 # (2, n_ch)
+        per_head = torch.zeros((2, nh), device=dev, dtype=per_ch.dtype).index_add_(1, head_of_ch, per_ch)
+        hm_loss = -per_head[0] / torch.clamp_min(per_head[1], 1.0) * lw['cls_weight']             # (nh,)
+        # ---- regression maps stacked over heads: (nh*B, c, H, W)
+        B = pred_dicts[0]['center'].shape[0]
+
+        def stk(name):
+            return torch.cat([p[name] for p in pred_dicts], dim=0)
+
+        center, center_z, dim_, rot, vel, iou = [stk(n) for n in ('center', 'center_z', 'dim', 'rot', 'vel', 'iou')]
+        inds = st['inds'].reshape(nh * B, -1)
+        masks = st['masks'].reshape(nh * B, -1)
+        K = inds.shape[1]
+        mb = masks.bool()
+        mf = masks.float()
+        n_head = mf.view(nh, -1).sum(1)                                                              # positives per head
+        pred_boxes = torch.cat([center, center_z, dim_, rot, vel], dim=1)                            # HEAD_ORDER minus iou
+        pred = loss_utils._transpose_and_gather_feat(pred_boxes, inds)                               # (nh*B, K, 10)
+        tgt = st['target_boxes'].reshape(nh * B, K, -1)
+        m = mf.unsqueeze(2) * (~torch.isnan(tgt)).float()
+        reg = torch.abs(pred * m - tgt * m).view(nh, B * K, -1).sum(1) / torch.clamp_min(n_head, 1.0).unsqueeze(1)     # (nh, 10)
+        loc_loss = (reg * reg.new_tensor(lw['code_weights'])).sum(1) * lw['loc_weight']             # (nh,)
+        # ---- decode every cell to a box (parity trap kept: int() truncates the range origin, radar_center_head.py:309-310)
+        batch_dim = torch.exp(torch.clamp(dim_, min=-5, max=5))
+        batch_rot = torch.atan2(rot[:, 1:2], rot[:, 0:1])
+        _, _, H, W = batch_dim.shape
+        ys, xs = torch.meshgrid(torch.arange(0, H, device=dev), torch.arange(0, W, device=dev), indexing='ij')
+        xs = xs.view(1, 1, H, W).to(batch_dim) + center[:, 0:1]
+        ys = ys.view(1, 1, H, W).to(batch_dim) + center[:, 1:2]
+        xs = xs * int(self.feature_map_stride) * self.voxel_size[0] + int(self.point_cloud_range[0])
+        ys = ys * int(self.feature_map_stride) * self.voxel_size[1] + int(self.point_cloud_range[1])
+        box_map = torch.cat([xs, ys, center_z, batch_dim, batch_rot], dim=1)                         # (nh*B, 7, H, W)
+        pb = loss_utils._masked_boxes(loss_utils._transpose_and_gather_feat(box_map, inds), mb)      # (nh*B, K, 7)
+        gtb = loss_utils._masked_boxes(st['gt_box'].reshape(nh * B, K, -1)[..., :7], mb)
+        # IouLoss: L1(iou head, 2*IoU3D(detached pred, gt) - 1) / (n + 1e-4)
+        iou_pred = loss_utils._transpose_and_gather_feat(iou, inds)                                  # (nh*B, K, 1)
+        target = loss_utils.iou3d_nms_utils.boxes_aligned_iou3d_gpu(pb.detach().reshape(-1, 7), gtb.reshape(-1, 7)).view(nh * B, K, 1)
+        iou_loss = (torch.abs(iou_pred - (2 * target - 1)) * mf.unsqueeze(-1)).view(nh, -1).sum(1) / (n_head + 1e-4)
+        # IouRegLoss (DIoU): sum(1 - diou) / (n + 1e-4)
+        diou = loss_utils.bbox3d_overlaps_diou(pb.reshape(-1, 7), gtb.reshape(-1, 7)).view(nh * B, K)
+        iou_reg_loss = ((1.0 - diou) * mf).view(nh, -1).sum(1) / (n_head + 1e-4)
+        per_head_total = hm_loss + loc_loss + iou_loss + lw['loc_weight'] * iou_reg_loss
+        loss = per_head_total.sum().view(1)
+        hm_d, loc_d, iou_d, reg_d = hm_loss.detach(), loc_loss.detach(), iou_loss.detach(), iou_reg_loss.detach()
+        for idx in range(nh):
+            tb_dict['hm_loss_head_%d' % idx] = hm_d[idx]
+            tb_dict['loc_loss_head_%d' % idx] = loc_d[idx]
+            tb_dict['iou_loss_head_%d' % idx] = iou_d[idx]
+            tb_dict['iou_reg_loss_head_%d' % idx] = reg_d[idx]
+        tb_dict['rpn_loss'] = loss.detach()
+        return loss, tb_dict
+
+    def get_loss_per_head(self):
         pred_dicts = self.forward_ret_dict['pred_dicts']
         target_dicts = self.forward_ret_dict['target_dicts']
         tb_dict = {}
@@ -248,8 +368,11 @@ class Radar_CenterHead(nn.Module):
         spatial_features_2d = data_dict[self.FEATURE_KEY]
         pred_dicts = self.head_forward(spatial_features_2d)
         if self.training:
-            target_dict = self.assign_targets(data_dict['gt_boxes'], feature_map_size=spatial_features_2d.size()[2:],
-                                              gt_boxes_host=data_dict.get('gt_boxes_host', None))
+            if data_dict['gt_boxes'].is_cuda and self.model_cfg.TARGET_ASSIGNER_CONFIG.get('DEVICE', 'gpu') == 'gpu' and not self.waymo:
+                target_dict = self.assign_targets_gpu(data_dict['gt_boxes'], spatial_features_2d.size()[2:])
+            else:
+                target_dict = self.assign_targets(data_dict['gt_boxes'], feature_map_size=spatial_features_2d.size()[2:],
+                                                  gt_boxes_host=data_dict.get('gt_boxes_host', None))
             self.forward_ret_dict['target_dicts'] = target_dict
             if self.model_cfg.get('DISTILL_PRED', None) and not self.IS_TEACHER:
                 data_dict['target_dicts'] = target_dict

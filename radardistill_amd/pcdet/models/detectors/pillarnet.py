@@ -23,8 +23,20 @@ class PillarNet(Detector3DTemplate):
         self.skip_unused_teacher_head = bool(self.model_cfg.get('SKIP_UNUSED_TEACHER_HEAD', False))
 
     def forward(self, batch_dict):
+        from radardistill_amd import autograd as A
+        dev = next(self.parameters()).device
+        if dev.type == "cuda":
+            A.begin_step(dev)
+        prepared = False
         for cur_module in self.module_list:
             cur_name = cur_module.__class__.__name__
+            if not prepared and hasattr(cur_module, 'prepare'):
+                # Build the active-site pyramids (rulebooks) of BOTH branches now, while the stream only holds the cheap VFE
+                # kernels: their device->host count read-backs then never wait behind convolution work.
+                for m in self.module_list:
+                    if hasattr(m, 'prepare'):
+                        m.prepare(batch_dict)
+                prepared = True
             if cur_name in self.no_grad_module:
                 cur_module.eval()
                 if self.skip_unused_teacher_head and cur_name == 'CenterHead' and self.training:
@@ -33,6 +45,8 @@ class PillarNet(Detector3DTemplate):
                     batch_dict = cur_module(batch_dict)
             else:
                 batch_dict = cur_module(batch_dict)
+        if dev.type == "cuda":
+            A.end_forward()
         if self.training:
             if self.model_cfg.get('DISTILL', None) is None:
                 loss, tb_dict, disp_dict = self.get_training_loss()
