@@ -97,17 +97,13 @@ def cpu_baseline(grid, B=4):
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from radardistill_amd import dist as D
+    world, rank, local_rank = D.env_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=device)     # "nccl" is RCCL on ROCm
+    D.init_distributed(backend="nccl", device=device)                 # "nccl" is RCCL on ROCm
     from radardistill_amd import kernels as K
     from radardistill_amd import native
     from radardistill_amd.pcdet.models import model_fn_decorator
@@ -121,13 +117,11 @@ def main():
     optimizer = build_optimizer(model, cfg.OPTIMIZATION)
     total_steps = args.steps + args.warmup
     sched, _ = build_scheduler(optimizer, max(total_steps, 10), 1, -1, cfg.OPTIMIZATION)
-    run_model = model
-    if world > 1:
-        run_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])
+    run_model = D.wrap_ddp(model, local_rank)
     model_func = model_fn_decorator()
     # a few distinct batches per rank, resident in HBM before timing; sample sharding: seed depends on the rank
     batches = [device_batch(make_batch(batch_size=args.batch, n_lidar=35000, n_radar=2000, n_boxes=30, grid=args.grid,
-                                       seed=1000 * rank + i), device) for i in range(2)]
+                                       seed=D.shard_seed(rank, i)), device) for i in range(2)]
 
     host_t = []
 
@@ -148,8 +142,7 @@ def main():
         step(it)
 
     def barrier():
-        if world > 1:
-            torch.distributed.barrier()
+        D.barrier()
         torch.cuda.synchronize()
 
     K.CONV_PROFILE = []
@@ -161,10 +154,7 @@ def main():
     dt = time.perf_counter() - t0
     prof, K.CONV_PROFILE = K.CONV_PROFILE, None
     last_loss = float(loss)
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = D.max_over_ranks(dt, device)
 
     if rank == 0:
         print(f"[bench] {args.steps} steps in {dt:.3f} s on {world} GPU(s)", file=sys.stderr, flush=True)
@@ -188,6 +178,12 @@ def main():
         n_launch = len(sel)
         avg_ms = sum(kernel_ms) / max(n_launch, 1)
         achieved = (sum(flops) / max(n_launch, 1)) / (avg_ms * 1e-3) / 1e12 if n_launch else 0.0
+        traffic = None          # HBM bytes per launch from the committed PMC passes (cannot be collected live inside bench.py)
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_hbm_traffic.json")))["kernels"]
+            traffic = next(v["hbm_bytes_per_launch_corrected"] for k, v in pm.items() if "k_conv_igemm<128, 128, 2, 2, false>" in k)
+        except Exception:
+            pass
         out = {
             "metric": "samples/sec", "value": round(samples / dt, 3), "unit": "samples/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
@@ -199,7 +195,7 @@ def main():
                        "teacher_head": "computed (unused by the loss, as in the reference)", "final_loss": last_loss},
             "roofline": {"bound": "mfma", "kernel": "k_conv_igemm<128,128,2,2,false> (gathered implicit-GEMM conv: sparse + dense 3x3 / 1x1 / transposed, fp32 MFMA)",
                          "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "launches_per_step": n_launch // max(args.steps, 1), "avg_launch_ms": round(avg_ms, 4),
                          "time_share_of_step": round(sum(kernel_ms) / (dt * 1e3), 4),
                          "all_mfma_conv_fwd_dgrad_share_of_step": round(sum(all_ms) / (dt * 1e3), 4)},

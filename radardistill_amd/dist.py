@@ -1,0 +1,62 @@
+"""One-process-per-GPU data parallelism helpers: process-group setup from the torchrun environment,
+sample sharding, DDP wrapping with the frozen teacher excluded, max-over-ranks timing and the logging reduction.
+
+Reference: tools/train.py:73-81,174-176 (init + DDP wrap), pcdet/utils/common_utils.py:169-211 (init_dist_pytorch),
+tools/train_utils/train_utils.py:73-75 (three `average_reduce_value` calls = 6 pickled all-gathers per step; here ONE
+all-reduce of a 3-float tensor, and only when something is logged).  Backend "nccl" is RCCL on ROCm; "gloo" is used by the
+CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_distributed(backend="nccl", device=None):
+    world, rank, local_rank = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        dist.init_process_group(backend=backend, **kw)
+    return world, rank, local_rank
+
+
+def shard_seed(rank, index, base=0):
+    """Seed of the `index`-th synthetic batch of rank `rank`: ranks never see the same samples (DistributedSampler role)."""
+    return base + 1000 * rank + index
+
+
+def wrap_ddp(model, local_rank=None):
+    """DistributedDataParallel over the trainable parameters only (frozen teacher parameters have requires_grad=False and are
+    ignored by the reducer, tools/train.py:174-176)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return model
+    ids = [local_rank] if (local_rank is not None and next(model.parameters()).is_cuda) else None
+    return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids)
+
+
+def max_over_ranks(seconds, device="cpu"):
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(seconds)
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def average_scalars(values, device="cpu"):
+    """Mean over ranks of a few python floats with ONE collective (data / forward / batch time of the reference's loop)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(v) for v in values]
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return (t / dist.get_world_size()).tolist()
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

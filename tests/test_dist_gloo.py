@@ -1,0 +1,75 @@
+"""World-size-2 gloo test (CPU) of the data-parallel glue used by bench.py / training for N > 1: process-group setup from
+the torchrun environment, per-rank sample sharding, DDP gradient averaging with frozen parameters excluded, max-over-ranks
+timing and the single-collective logging reduction."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from radardistill_amd import dist as D
+    from radardistill_amd.synthetic import make_batch
+    import torch.distributed as dist
+    w, r, lr = D.init_distributed(backend="gloo")
+    assert (w, r) == (world, rank)
+    # sample sharding: distinct synthetic samples per rank
+    b = make_batch(batch_size=1, n_lidar=50, n_radar=20, n_boxes=2, grid=128, seed=D.shard_seed(rank, 0))
+    csum = float(b["radar_points"].sum())
+    # DDP: frozen "teacher" + trainable "student"; gradients are averaged over ranks, frozen params untouched
+    torch.manual_seed(0)
+    net = torch.nn.ModuleDict({"teacher": torch.nn.Linear(4, 4), "student": torch.nn.Linear(4, 2)})
+    for p in net["teacher"].parameters():
+        p.requires_grad = False
+
+    class M(torch.nn.Module):
+        def __init__(self, net):
+            super().__init__(); self.net = net
+
+        def forward(self, x):
+            with torch.no_grad():
+                t = self.net["teacher"](x)
+            return self.net["student"](t)
+
+    m = D.wrap_ddp(M(net))
+    x = torch.full((3, 4), float(rank + 1))
+    m(x).sum().backward()
+    g = net["student"].weight.grad.clone()
+    t_max = D.max_over_ranks(0.1 * (rank + 1))
+    avg = D.average_scalars([float(rank), 10.0 * rank, 1.0])
+    D.barrier()
+    q.put((rank, csum, g.numpy(), t_max, avg, net["teacher"].weight.grad is None))
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, c0, g0, t0, a0, f0), (r1, c1, g1, t1, a1, f1) = res
+    assert c0 != c1                                         # ranks got different samples
+    np.testing.assert_allclose(g0, g1)                      # DDP left identical (averaged) gradients on both ranks
+    # expected: mean over ranks of d/dW sum(W t): rows of t summed -> 3 * teacher(x_rank)
+    torch.manual_seed(0)
+    teacher = torch.nn.Linear(4, 4)
+    exp = sum(3 * teacher(torch.full((1, 4), float(r + 1))).detach()[0] for r in range(2)) / 2
+    np.testing.assert_allclose(g0, np.tile(exp.numpy(), (2, 1)), rtol=1e-5)
+    assert abs(t0 - 0.2) < 1e-9 and abs(t1 - 0.2) < 1e-9     # max over ranks
+    assert a0 == a1 == [0.5, 5.0, 1.0]
+    assert f0 and f1                                         # frozen parameters received no gradient

@@ -277,6 +277,7 @@ def test_batchnorm_train_forward_backward(C, rows, act, res):
     if res:
         close(rd.grad, rr.grad)
     close(bd.running_mean, bn.running_mean); close(bd.running_var, bn.running_var)
+    A.end_forward()            # num_batches_tracked is bumped for all train-mode BatchNorms of a forward in one launch
     assert int(bd.num_batches_tracked) == 1
 
 
