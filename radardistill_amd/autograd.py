@@ -58,6 +58,42 @@ class _ZeroArena:
 
 
 ARENA = _ZeroArena()
+_ARENA_STACK = []
+_CONST = {}
+
+
+def const_tensor(key, values, device, dtype=torch.float32):
+    """Small constant tensors (loss weights, safe boxes, channel->head maps) uploaded once: host->device copies are not
+    allowed inside a HIP-graph capture."""
+    k = (key, str(device), dtype)
+    t = _CONST.get(k)
+    if t is None:
+        t = _CONST[k] = torch.tensor(values, dtype=dtype, device=device)
+    return t
+
+
+class private_arena:
+    """Route zero-scratch requests to a dedicated arena (a HIP-graph section owns its scratch and re-zeroes it inside the graph)."""
+
+    def __init__(self, arena, device):
+        self.arena, self.device = arena, device
+
+    def __enter__(self):
+        global ARENA
+        _ARENA_STACK.append((ARENA, list(_BN_TOUCHED)))
+        ARENA = self.arena
+        _BN_TOUCHED.clear()
+        self.arena.begin_step(self.device)
+        return self.arena
+
+    def __exit__(self, *exc):
+        global ARENA
+        end_forward()
+        ARENA, touched = _ARENA_STACK.pop()
+        _BN_TOUCHED.extend(touched)
+        return False
+
+
 _BN_TOUCHED = []          # BatchNorm modules that ran in train mode this step (num_batches_tracked bumped once, together)
 
 
@@ -77,21 +113,27 @@ def zeros_stats(n, device):
     return ARENA.take(n, device)
 
 
+def zeros_accum(n, device):
+    return ARENA.take(n, device)
+
+
 def kernel_weight(param, Cout, Cin, taps, kind, flip=False):
     """Parameter -> kernel layout [Cout][taps][Cin] (or its data-gradient transpose), cached per parameter version."""
-    key = (id(param), kind, flip)
-    ver = (param._version, _WEIGHTS_EPOCH[0], param.data_ptr())
-    hit = _LAYOUT_CACHE.get(key)
-    if hit is not None and hit[0] == ver:
-        return hit[1]
     src = param.detach()
     if not src.is_contiguous():
         src = src.contiguous()
     if kind == 0 and not flip:
-        w = src.reshape(Cout, taps, Cin)          # spconv layout [Cout,kh,kw,Cin] and nn.Linear [Cout,Cin] are already kernel layout
-    else:
-        w = K.weight_layout(src, Cout, Cin, taps, kind, flip)
-    _LAYOUT_CACHE[key] = (ver, w)
+        return src.reshape(Cout, taps, Cin)       # spconv layout [Cout,kh,kw,Cin] and nn.Linear [Cout,Cin] are already kernel layout
+    capturing = param.is_cuda and torch.cuda.is_current_stream_capturing()
+    key = (id(param), kind, flip)
+    ver = (param._version, _WEIGHTS_EPOCH[0], param.data_ptr())
+    if not capturing or not param.requires_grad:
+        hit = _LAYOUT_CACHE.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+    w = K.weight_layout(src, Cout, Cin, taps, kind, flip)
+    if not capturing:                             # inside a HIP-graph capture the re-layout must be part of the graph (weights change between replays)
+        _LAYOUT_CACHE[key] = (ver, w)
     return w
 
 
@@ -240,8 +282,9 @@ def bn_eval_scale_shift(bn):
     unchanged (the frozen teacher: computed once instead of 4 small launches per layer per step)."""
     ver = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, _WEIGHTS_EPOCH[0] if bn.weight.requires_grad else -1,
            bn.weight.data_ptr(), bn.running_var.data_ptr())
+    capturing = bn.weight.is_cuda and torch.cuda.is_current_stream_capturing() and bn.weight.requires_grad
     hit = _BN_FOLD_CACHE.get(id(bn))
-    if hit is not None and hit[0] == ver:
+    if hit is not None and hit[0] == ver and not capturing:
         return hit[1], hit[2]
     with torch.no_grad():
         rstd = torch.rsqrt(bn.running_var + bn.eps)

@@ -205,7 +205,7 @@ def conv_wgrad(x, grad_out, taps, ix):
     in_rows, Cin = x.shape
     out_rows, Cout = grad_out.shape
     from . import autograd as _A
-    gw = _A.ARENA.take(Cout * taps * Cin, x.device).view(Cout, taps, Cin)          # zero-initialised accumulator (atomics)
+    gw = _A.zeros_accum(Cout * taps * Cin, x.device).view(Cout, taps, Cin)          # zero-initialised accumulator (atomics)
     check(native.lib().rd_conv_wgrad(_p(x), in_rows, Cin, _p(grad_out), out_rows, Cout, taps, ctypes.byref(ix), _p(gw), _stream()), "rd_conv_wgrad")
     return gw
 

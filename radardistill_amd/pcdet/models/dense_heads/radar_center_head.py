@@ -255,7 +255,7 @@ class Radar_CenterHead(nn.Module):
         tb_dict = {}
         # ---- focal loss on all heat-map channels at once; per-head normalisation by that head's positives
         nc = [p['hm'].shape[1] for p in pred_dicts]
-        head_of_ch = torch.repeat_interleave(torch.arange(nh), torch.tensor(nc)).to(dev)
+        head_of_ch = A.const_tensor(("head_of_ch", tuple(nc)), [h for h, c in enumerate(nc) for _ in range(c)], dev, torch.int64)
         hm = self.sigmoid(torch.cat([p['hm'] for p in pred_dicts], dim=1))
         gt = st['heatmaps']
         pos_inds = gt.eq(1).float()
@@ -283,7 +283,7 @@ class Radar_CenterHead(nn.Module):
         tgt = st['target_boxes'].reshape(nh * B, K, -1)
         m = mf.unsqueeze(2) * (~torch.isnan(tgt)).float()
         reg = torch.abs(pred * m - tgt * m).view(nh, B * K, -1).sum(1) / torch.clamp_min(n_head, 1.0).unsqueeze(1)     # (nh, 10)
-        loc_loss = (reg * reg.new_tensor(lw['code_weights'])).sum(1) * lw['loc_weight']             # (nh,)
+        loc_loss = (reg * A.const_tensor("code_weights", list(lw['code_weights']), dev)).sum(1) * lw['loc_weight']     # (nh,)
         # ---- decode every cell to a box (parity trap kept: int() truncates the range origin, radar_center_head.py:309-310)
         batch_dim = torch.exp(torch.clamp(dim_, min=-5, max=5))
         batch_rot = torch.atan2(rot[:, 1:2], rot[:, 0:1])

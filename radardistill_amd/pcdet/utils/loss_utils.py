@@ -84,7 +84,8 @@ _SAFE_BOX = None
 
 def _masked_boxes(boxes, mask_b):
     """Replace masked-out (all-zero gt / arbitrary pred) slots by a harmless unit box so no NaN/inf reaches the masked sum."""
-    safe = boxes.new_tensor([0.0, 0.0, 0.0, 1.0, 1.0, 1.0, 0.0])
+    from radardistill_amd.autograd import const_tensor
+    safe = const_tensor("safe_box", [0.0, 0.0, 0.0, 1.0, 1.0, 1.0, 0.0], boxes.device, boxes.dtype)
     return torch.where(mask_b.unsqueeze(-1), boxes, safe.expand_as(boxes))
 
 
