@@ -46,6 +46,10 @@ class _ZeroArena:
         self.off = 0
 
     def take(self, n, device):
+        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            # inside a HIP-graph capture (forward OR the separately captured backward): the fill must be a node of that graph
+            # and the memory must belong to the graph's pool; the arena (re-zeroed outside the graph) is for eager code only
+            return torch.zeros(n, dtype=torch.float32, device=device)
         n_al = (n + 63) // 64 * 64
         if self.buf is None or self.buf.device != device or self.off + n_al > self.buf.numel():
             self.high = max(self.high, self.off + n_al)          # grow on the next step; this request falls back to a fresh tensor

@@ -6,7 +6,8 @@ assignment + AFD/PFD/detection losses and their whole backward.  That is ~80 % o
 host cannot enqueue them as fast as the GPU runs them.  Captured once (after warm-up) and replayed per step, the host cost
 of the section drops to two graph launches.  All librdamd entry points only enqueue on the given stream and take caller
 memory, so they are capturable; caches that would hide weight re-layout kernels from the capture are bypassed while
-capturing (autograd.kernel_weight), scratch comes from a private zero arena re-zeroed inside the graph.
+capturing (autograd.kernel_weight), and zero-initialised scratch is allocated inside the capture (graph pool + fill node)
+instead of the eager per-step arena.
 """
 import torch
 import torch.nn as nn
@@ -36,21 +37,20 @@ class _StudentDense(nn.Module):
     def __init__(self, model):
         super().__init__()
         self.r2d, self.rhead = model.radar_backbone_2d, model.radar_dense_head
-        self.arena = A._ZeroArena()
         self.tb_names = None
 
     def forward(self, s4, s5, t4, l2d, l2d8, gt):
-        with A.private_arena(self.arena, s4.device):
-            bd = {'radar_multi_scale_2d_features': {'x_conv4': s4, 'x_conv5': s5}, 'multi_scale_2d_features': {'x_conv4': t4},
-                  'spatial_features_2d': l2d, 'spatial_features_2d_8x': l2d8, 'gt_boxes': gt, 'batch_size': s4.shape[0]}
-            bd = self.rhead(self.r2d(bd))
-            loss_feature, tb = self.r2d.get_loss(bd)
-            loss_rpn, tb2 = self.rhead.get_loss()
-            tb.update(tb2)
-            loss = (loss_feature + loss_rpn).mean()
-            self.tb_names = list(tb.keys())
-            vals = torch.stack([v.detach().reshape(()).float() for v in tb.values()])
-            return torch.cat([loss.reshape(1), vals])
+        bd = {'radar_multi_scale_2d_features': {'x_conv4': s4, 'x_conv5': s5}, 'multi_scale_2d_features': {'x_conv4': t4},
+              'spatial_features_2d': l2d, 'spatial_features_2d_8x': l2d8, 'gt_boxes': gt, 'batch_size': s4.shape[0]}
+        bd = self.rhead(self.r2d(bd))
+        A.end_forward()                 # num_batches_tracked of this section's BatchNorms: part of the captured graph
+        loss_feature, tb = self.r2d.get_loss(bd)
+        loss_rpn, tb2 = self.rhead.get_loss()
+        tb.update(tb2)
+        loss = (loss_feature + loss_rpn).mean()
+        self.tb_names = list(tb.keys())
+        vals = torch.stack([v.detach().reshape(()).float() for v in tb.values()])
+        return torch.cat([loss.reshape(1), vals])
 
 
 class _GraphedInference:

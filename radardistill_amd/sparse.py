@@ -23,7 +23,8 @@ _RANKGRID_REGISTRY = {}
 
 
 def register_rankgrid(coords, rankgrid, xmajor):
-    _RANKGRID_REGISTRY.clear()      # one live entry per producer is enough; avoids keeping old steps alive
+    while len(_RANKGRID_REGISTRY) >= 4:          # teacher + student of the current step (+ the previous step's); bounded
+        _RANKGRID_REGISTRY.pop(next(iter(_RANKGRID_REGISTRY)))
     _RANKGRID_REGISTRY[(coords.data_ptr(), tuple(coords.shape))] = (rankgrid, xmajor, coords)
 
 
