@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="samples per GPU (BATCH_SIZE_PER_GPU of the reference yaml)")
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--math", choices=["f32", "bf16x3"], default="f32", help="arithmetic of the implicit-GEMM conv kernels")
     ap.add_argument("--graphs", type=int, default=1, help="1: replay the static-shape dense section as captured HIP graphs")
     ap.add_argument("--cpu-baseline-grid", type=int, default=512)
     ap.add_argument("--cpu-baseline-batch", type=int, default=4)
@@ -113,6 +114,7 @@ def main():
     if native.lib().rd_device_ok() != 1:
         raise SystemExit("bench.py: no gfx950 device visible to librdamd.so")
 
+    K.set_conv_math(args.math)
     model, cfg, geom = build(os.path.join(ROOT, "tools/cfgs/radar_distill/bench_512.yaml"), args.grid, device)
     model.train()
     model.use_graphs = bool(args.graphs)
@@ -205,7 +207,7 @@ def main():
             "config": {"workload": "RadarDistill full training step (BASELINE configs[3]): frozen LiDAR teacher fwd + radar student "
                                    "fwd/bwd (VFE, SparseEnc, CMA+DCNv2, DenseEnc, CenterHead, AFD+PFD+detection losses) + clip + Adam",
                        "bev": f"{args.grid}x{args.grid}", "pillar_m": 0.2, "lidar_pts": 35000, "radar_pts": 2000, "boxes": 30,
-                       "hip_graphs": bool(args.graphs), "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "hip_graphs": bool(args.graphs), "conv_math": args.math, "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "teacher_head": "computed (unused by the loss, as in the reference)", "final_loss": last_loss},
             "roofline": {"bound": "mfma", "kernel": "k_conv_igemm<128,128,2,2,false> (gathered implicit-GEMM conv: sparse + dense 3x3 / 1x1 / transposed, fp32 MFMA)",
                          "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -124,6 +124,11 @@ int rd_conv_fwd(const float *in, int in_rows, int Cin, const float *weight_k, in
                 float *out, int out_rows, int Cout, const rd_conv_index *idx,
                 const float *scale, const float *shift, const float *residual, int relu, float *stats, void *stream);
 
+/* Arithmetic of rd_conv_fwd for Cout > 32: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32, default); 1 = "bf16x3": operands split
+ * into bf16 hi + lo while staged, three bf16 MFMAs per product, fp32 accumulate (~4e-6 relative error, 5x fewer matrix cycles). */
+int rd_set_conv_math(int mode);
+int rd_get_conv_math(void);
+
 /* Weight gradient: grad_wk[Cout][taps][Cin] += sum_j grad_out[j][:]^T (x) in[src(j,t)][:]  (atomic accumulation,
  * caller zeroes).  Cout % 32 == 0 or Cout < 32 handled by masking; Cin % 32 == 0. */
 int rd_conv_wgrad(const float *in, int in_rows, int Cin, const float *grad_out, int out_rows, int Cout, int taps,

@@ -12,59 +12,9 @@
 // tile has a source are skipped (sparse rulebooks are far from full at the shallow stages).
 // MFMA operand maps (guide section 3): A: lane l holds A[i = l&31][k = l>>5]; B: B[k = l>>5][j = l&31];
 // C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
-#include "common.hpp"
+#include "conv_common.hpp"
 
 using namespace rd;
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int KB = 32;
-constexpr int LDK = KB + 4;  // padded LDS row (floats)
-constexpr int MAX_TAPS = 16;
-
-struct ConvArgs {
-    const float *in;
-    int in_rows, Cin;
-    const float *w;
-    int taps;
-    const float *bias;
-    float *out;
-    int out_rows, Cout;
-    rd_conv_index ix;
-    const float *scale, *shift, *residual;
-    int relu;
-    float *stats;
-};
-
-__device__ __forceinline__ int src_row(const ConvArgs &a, int j, int t) {
-    if (j >= a.out_rows) return -1;
-    const rd_conv_index &ix = a.ix;
-    if (ix.mode == 0) {
-        int tt = ix.flip ? (a.taps - 1 - t) : t;
-        return ix.nbr[(int64_t)j * a.taps + tt];
-    }
-    if (ix.mode == 3) {  // deformable sampling: "has a source" == any of the 4 bilinear corners is inside the map
-        const int4 q = *reinterpret_cast<const int4 *>(ix.samp_idx + ((int64_t)j * a.taps + t) * 4);
-        return max(max(q.x, q.y), max(q.z, q.w));
-    }
-    int ox = j % ix.Wout;
-    int oy = (j / ix.Wout) % ix.Hout;
-    int b = j / (ix.Wout * ix.Hout);
-    int ky = t / ix.KW, kx = t % ix.KW;
-    int iy, ixx;
-    if (ix.mode == 1) {
-        iy = oy * ix.stride - ix.pad + ky;
-        ixx = ox * ix.stride - ix.pad + kx;
-    } else {  // transposed: oy = iy*stride - pad + ky
-        int ny = oy + ix.pad - ky, nx = ox + ix.pad - kx;
-        if (ny < 0 || nx < 0 || (ny % ix.stride) || (nx % ix.stride)) return -1;
-        iy = ny / ix.stride;
-        ixx = nx / ix.stride;
-    }
-    if (iy < 0 || iy >= ix.Hin || ixx < 0 || ixx >= ix.Win) return -1;
-    return (b * ix.Hin + iy) * ix.Win + ixx;
-}
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool DEFORM>
 __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
@@ -79,7 +29,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WAVES_N, wn = wid % WAVES_N;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    int row_tile, col_tile;
+    if (!xcd_tile((a.out_rows + BM - 1) / BM, (a.Cout + BN - 1) / BN, row_tile, col_tile)) return;
+    const int m0 = row_tile * BM, n0 = col_tile * BN;
     const int ld_r = tid >> 3, ld_c = (tid & 7) * 4;
 
     // ---- which taps have any source row in this tile
@@ -263,6 +215,16 @@ static int validate_index(const rd_conv_index *ix, int taps, int in_rows, int ou
     return RD_OK;
 }
 
+// 0 = exact fp32 MFMA (default), 1 = bf16x3 split MFMA (conv_b3.hip)
+static int g_conv_math = 0;
+int launch_conv_b3(const ConvArgs &a, int mode, hipStream_t st);
+extern "C" int rd_set_conv_math(int mode) {
+    RD_REQUIRE(mode == 0 || mode == 1, "rd_set_conv_math: mode must be 0 (f32) or 1 (bf16x3)");
+    g_conv_math = mode;
+    return RD_OK;
+}
+extern "C" int rd_get_conv_math(void) { return g_conv_math; }
+
 extern "C" int rd_conv_fwd(const float *in, int in_rows, int Cin, const float *weight_k, int taps, const float *bias, float *out,
                            int out_rows, int Cout, const rd_conv_index *idx, const float *scale, const float *shift,
                            const float *residual, int relu, float *stats, void *stream) {
@@ -274,35 +236,39 @@ extern "C" int rd_conv_fwd(const float *in, int in_rows, int Cin, const float *w
     ConvArgs a{in, in_rows, Cin, weight_k, taps, bias, out, out_rows, Cout, *idx, scale, shift, residual, relu, stats};
     hipStream_t st = S(stream);
     dim3 block(256);
+    if (g_conv_math == 1 && Cout > 32) {
+        launch_conv_b3(a, idx->mode, st);
+        return check_launch("rd_conv_fwd(bf16x3)");
+    }
     // Tile choice: 128x128 when that already gives every CU two workgroups (512 resident blocks), otherwise 64x64 tiles
     // (4x the workgroups; operands are L2-resident at these sizes, so the extra re-reads stay on chip).
     const int64_t big_blocks = cdiv(out_rows, 128) * cdiv(Cout, 128);
     if (idx->mode == 3) {
         if (big_blocks >= 384) {
-            dim3 grid((unsigned)cdiv(out_rows, 128), (unsigned)cdiv(Cout, 128));
+            dim3 grid(xcd_grid(cdiv(out_rows, 128), cdiv(Cout, 128)));
             k_conv_igemm<128, 128, 2, 2, true><<<grid, block, 0, st>>>(a);
         } else {
-            dim3 grid((unsigned)cdiv(out_rows, 64), (unsigned)cdiv(Cout, 64));
+            dim3 grid(xcd_grid(cdiv(out_rows, 64), cdiv(Cout, 64)));
             k_conv_igemm<64, 64, 2, 2, true><<<grid, block, 0, st>>>(a);
         }
     } else if (Cout > 64) {
         if (big_blocks >= 384) {
-            dim3 grid((unsigned)cdiv(out_rows, 128), (unsigned)cdiv(Cout, 128));
+            dim3 grid(xcd_grid(cdiv(out_rows, 128), cdiv(Cout, 128)));
             k_conv_igemm<128, 128, 2, 2, false><<<grid, block, 0, st>>>(a);
         } else {
-            dim3 grid((unsigned)cdiv(out_rows, 64), (unsigned)cdiv(Cout, 64));
+            dim3 grid(xcd_grid(cdiv(out_rows, 64), cdiv(Cout, 64)));
             k_conv_igemm<64, 64, 2, 2, false><<<grid, block, 0, st>>>(a);
         }
     } else if (Cout > 32) {
         if (cdiv(out_rows, 128) >= 384) {
-            dim3 grid((unsigned)cdiv(out_rows, 128), 1);
+            dim3 grid(xcd_grid(cdiv(out_rows, 128), 1));
             k_conv_igemm<128, 64, 2, 2, false><<<grid, block, 0, st>>>(a);
         } else {
-            dim3 grid((unsigned)cdiv(out_rows, 64), 1);
+            dim3 grid(xcd_grid(cdiv(out_rows, 64), 1));
             k_conv_igemm<64, 64, 2, 2, false><<<grid, block, 0, st>>>(a);
         }
     } else {
-        dim3 grid((unsigned)cdiv(out_rows, 128), 1);
+        dim3 grid(xcd_grid(cdiv(out_rows, 128), 1));
         k_conv_igemm<128, 32, 4, 1, false><<<grid, block, 0, st>>>(a);
     }
     return check_launch("rd_conv_fwd");

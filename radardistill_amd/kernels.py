@@ -439,3 +439,14 @@ def center_targets(gt_boxes, cfg_struct):
     check(native.lib().rd_center_targets(_p(gt_boxes), B, M, D, ctypes.byref(c), _p(hm), _p(tb), _p(inds), _p(masks), _p(gb), _stream()),
           "rd_center_targets")
     return {"heatmaps": hm, "target_boxes": tb, "inds": inds, "masks": masks, "gt_box": gb}
+
+
+# ------------------------------------------------------------------------------------------ arithmetic mode of the conv kernels
+def set_conv_math(mode):
+    """'f32': exact fp32 MFMA (default).  'bf16x3': split-bf16 MFMA, ~4e-6 relative error (conv_b3.hip)."""
+    code = {"f32": 0, "bf16x3": 1}[mode]
+    check(native.lib().rd_set_conv_math(code), "rd_set_conv_math")
+
+
+def get_conv_math():
+    return {0: "f32", 1: "bf16x3"}[native.lib().rd_get_conv_math()]
