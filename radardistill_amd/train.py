@@ -74,9 +74,16 @@ class FusedAdamOneCycle:
                 chunks.append((i, off))
         self.n_chunks = len(chunks)
         self.chunks_dev = torch.tensor(chunks, dtype=torch.int32, device=dev).contiguous()
-        self.table_host = torch.empty(len(self.params) * ctypes.sizeof(_OptTensor), dtype=torch.uint8).pin_memory() \
-            if dev.type == "cuda" else torch.empty(len(self.params) * ctypes.sizeof(_OptTensor), dtype=torch.uint8)
-        self.table_dev = torch.empty_like(self.table_host, device=dev)
+        # Descriptor tables go host -> device asynchronously every step (gradient tensors are new allocations each step).  The host
+        # may run a whole step ahead of the GPU (HIP-graph replay), so the pinned staging buffer is a ring: a slot is rewritten only
+        # after the copy that read it has completed (event), never while a DMA may still be reading it.
+        nbytes = len(self.params) * ctypes.sizeof(_OptTensor)
+        self._ring = 4
+        self._slot = 0
+        self.table_host = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() if dev.type == "cuda" else torch.empty(nbytes, dtype=torch.uint8)
+                           for _ in range(self._ring)]
+        self.table_dev = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(self._ring)]
+        self._copied = [None] * self._ring
         self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)
         self.ws = torch.empty(self.n_chunks, dtype=torch.float32, device=dev)
         self._zero = {}
@@ -86,7 +93,12 @@ class FusedAdamOneCycle:
             p.grad = None
 
     def _fill_table(self):
-        arr = (_OptTensor * len(self.params)).from_buffer(self.table_host.numpy())
+        self._slot = (self._slot + 1) % self._ring
+        ev = self._copied[self._slot]
+        if ev is not None:
+            ev.synchronize()                   # the copy issued `ring` steps ago out of this slot (and the kernels that read the
+        host, dev_t = self.table_host[self._slot], self.table_dev[self._slot]     # device copy, stream-ordered before it) are done
+        arr = (_OptTensor * len(self.params)).from_buffer(host.numpy())
         m0, v0 = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
         for i, p in enumerate(self.params):
             g = p.grad
@@ -101,19 +113,24 @@ class FusedAdamOneCycle:
             arr[i].exp_avg = m0 + 4 * int(self.offsets[i])
             arr[i].exp_avg_sq = v0 + 4 * int(self.offsets[i])
             arr[i].numel = p.numel()
-        self.table_dev.copy_(self.table_host, non_blocking=True)
+        dev_t.copy_(host, non_blocking=True)
+        if dev_t.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._copied[self._slot] = ev
+        return dev_t
 
     def step(self):
         """clip_grad_norm_(grad_clip) + OptimWrapper.step(); returns the device tensor [total_norm, clip_coef]."""
-        self._fill_table()
+        table = self._fill_table()
         L = native.lib()
         clip = None
         if self.grad_clip is not None and self.grad_clip > 0:
-            check(L.rd_grad_norm(_p(self.table_dev), _p(self.chunks_dev), self.n_chunks, float(self.grad_clip), _p(self.norm_out),
+            check(L.rd_grad_norm(_p(table), _p(self.chunks_dev), self.n_chunks, float(self.grad_clip), _p(self.norm_out),
                                  _p(self.ws), self.ws.numel() * 4, _stream()), "rd_grad_norm")
             clip = self.norm_out
         self.step_count += 1
-        check(L.rd_adam_step(_p(self.table_dev), _p(self.chunks_dev), self.n_chunks, float(self.lr), float(self.mom), float(self.beta2),
+        check(L.rd_adam_step(_p(table), _p(self.chunks_dev), self.n_chunks, float(self.lr), float(self.mom), float(self.beta2),
                              float(self.eps), float(self.wd), self.step_count, _p(clip), _stream()), "rd_adam_step")
         A.bump_weights_epoch()                 # parameters changed through raw pointers: invalidate cached weight layouts
         return self.norm_out

