@@ -27,6 +27,25 @@ def bump_weights_epoch():
     _WEIGHTS_EPOCH[0] += 1
 
 
+# > 0 while radardistill_amd.graphs is warming up / capturing a HIP graph.  Checked in addition to
+# torch.cuda.is_current_stream_capturing(): the captured BACKWARD runs on the autograd engine's thread, and anything that must
+# not leak eager-only state (per-step arena memory, cached weight layouts) into a graph has to see the capture from there too.
+_CAPTURE_DEPTH = [0]
+
+
+class capture_scope:
+    def __enter__(self):
+        _CAPTURE_DEPTH[0] += 1
+
+    def __exit__(self, *exc):
+        _CAPTURE_DEPTH[0] -= 1
+        return False
+
+
+def in_capture(device_is_cuda=True):
+    return _CAPTURE_DEPTH[0] > 0 or (device_is_cuda and torch.cuda.is_current_stream_capturing())
+
+
 class _ZeroArena:
     """Per-step pool of zero-initialised fp32 scratch (BatchNorm statistics, weight-gradient accumulators): ONE memset per
     step instead of one torch.zeros launch per layer.  `begin_step()` re-zeroes and rewinds; slices stay valid until the next
@@ -46,7 +65,7 @@ class _ZeroArena:
         self.off = 0
 
     def take(self, n, device):
-        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+        if in_capture(device.type == "cuda"):
             # inside a HIP-graph capture (forward OR the separately captured backward): the fill must be a node of that graph
             # and the memory must belong to the graph's pool; the arena (re-zeroed outside the graph) is for eager code only
             return torch.zeros(n, dtype=torch.float32, device=device)
@@ -128,7 +147,7 @@ def kernel_weight(param, Cout, Cin, taps, kind, flip=False):
         src = src.contiguous()
     if kind == 0 and not flip:
         return src.reshape(Cout, taps, Cin)       # spconv layout [Cout,kh,kw,Cin] and nn.Linear [Cout,Cin] are already kernel layout
-    capturing = param.is_cuda and torch.cuda.is_current_stream_capturing()
+    capturing = in_capture(param.is_cuda)
     key = (id(param), kind, flip)
     ver = (param._version, _WEIGHTS_EPOCH[0], param.data_ptr())
     if not capturing or not param.requires_grad:
@@ -286,7 +305,7 @@ def bn_eval_scale_shift(bn):
     unchanged (the frozen teacher: computed once instead of 4 small launches per layer per step)."""
     ver = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, _WEIGHTS_EPOCH[0] if bn.weight.requires_grad else -1,
            bn.weight.data_ptr(), bn.running_var.data_ptr())
-    capturing = bn.weight.is_cuda and torch.cuda.is_current_stream_capturing() and bn.weight.requires_grad
+    capturing = in_capture(bn.weight.is_cuda) and bn.weight.requires_grad
     hit = _BN_FOLD_CACHE.get(id(bn))
     if hit is not None and hit[0] == ver and not capturing:
         return hit[1], hit[2]

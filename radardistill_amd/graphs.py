@@ -70,15 +70,16 @@ class _GraphedInference:
 
     def _capture(self, args, key):
         self.static_in = [a.detach().clone() for a in args]
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                self.module(*self.static_in)
-        torch.cuda.current_stream().wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.static_out = self.module(*self.static_in)
+        with A.capture_scope():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self.module(*self.static_in)
+            torch.cuda.current_stream().wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.static_out = self.module(*self.static_in)
         self.key = key
 
 
@@ -103,7 +104,8 @@ class DenseSectionGraphs:
             saved = [b.detach().clone() for b in self._buffers()]
             self.student_module.train()
             sample = tuple(a.detach().clone().requires_grad_(a.requires_grad) for a in args)
-            self.student = torch.cuda.make_graphed_callables(self.student_module, sample, allow_unused_input=True)
+            with A.capture_scope():     # warm-up + forward capture + backward capture (the latter on the autograd thread)
+                self.student = torch.cuda.make_graphed_callables(self.student_module, sample, allow_unused_input=True)
             for b, s in zip(self._buffers(), saved):
                 b.copy_(s)
             self.key = key
