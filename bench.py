@@ -35,7 +35,8 @@ def parse():
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--math", choices=["f32", "bf16x3"], default="f32", help="arithmetic of the implicit-GEMM conv kernels")
-    ap.add_argument("--graphs", type=int, default=1, help="1: replay the static-shape dense section as captured HIP graphs")
+    ap.add_argument("--graphs", type=int, default=0, help="1: replay the static-shape dense section as captured HIP graphs "
+                    "(experimental: see DESIGN.md section 7)")
     ap.add_argument("--cpu-baseline-grid", type=int, default=512)
     ap.add_argument("--cpu-baseline-batch", type=int, default=4)
     return ap.parse_args()

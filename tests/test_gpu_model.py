@@ -325,7 +325,8 @@ def test_center_targets_gpu_kernel_vs_reference_host_loops(grid, B, n_boxes):
 
 
 def test_hip_graph_dense_section_matches_eager():
-    """Training steps with the dense section replayed from captured HIP graphs vs eagerly.
+    """(Experimental feature, off by default -- DESIGN.md section 7.)  Training steps with the dense section replayed from
+    captured HIP graphs vs eagerly.
 
     Step 0 (identical weights): loss, every tb entry and every gradient agree (per-tensor relative L2; the bound is the
     process-to-process spread of the eager path itself: fp32 atomics order -> ReLU sign flips, measured with
