@@ -90,23 +90,11 @@ class DenseSectionGraphs:
         self.student_module = _StudentDense(model)
         self.student = None
         self.key = None
-        self.eager_calls = 0        # the first call of a process runs the section eagerly (lazy one-time initialisation of the
-                                    # runtime / allocator happens outside any capture); capture starts with the second call
 
     def _buffers(self):
         return [b for m in (self.student_module.r2d, self.student_module.rhead) for b in m.buffers()]
 
-    def run_eager(self, s4, s5, t4, t5, gt):
-        touts = self.teacher.module(t4, t5)
-        out = self.student_module(s4, s5, t4.detach(), touts[1], touts[0], gt)
-        vals = out.detach()
-        tb = {n: vals[1 + i] for i, n in enumerate(self.student_module.tb_names)}
-        return out[0], tb, (touts[0], touts[1])
-
     def run(self, s4, s5, t4, t5, gt):
-        if self.eager_calls < 1:
-            self.eager_calls += 1
-            return self.run_eager(s4, s5, t4, t5, gt)
         touts = self.teacher(t4, t5)
         l2d8, l2d = touts[0], touts[1]
         args = (s4, s5, t4.detach(), l2d, l2d8, gt)
