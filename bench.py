@@ -35,8 +35,6 @@ def parse():
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--math", choices=["f32", "bf16x3"], default="f32", help="arithmetic of the implicit-GEMM conv kernels")
-    ap.add_argument("--graphs", type=int, default=0, help="1: replay the static-shape dense section as captured HIP graphs "
-                    "(experimental: see DESIGN.md section 7)")
     ap.add_argument("--cpu-baseline-grid", type=int, default=512)
     ap.add_argument("--cpu-baseline-batch", type=int, default=4)
     return ap.parse_args()
@@ -118,7 +116,6 @@ def main():
     K.set_conv_math(args.math)
     model, cfg, geom = build(os.path.join(ROOT, "tools/cfgs/radar_distill/bench_512.yaml"), args.grid, device)
     model.train()
-    model.use_graphs = bool(args.graphs)
     optimizer = build_optimizer(model, cfg.OPTIMIZATION)
     total_steps = args.steps + args.warmup
     sched, _ = build_scheduler(optimizer, max(total_steps, 10), 1, -1, cfg.OPTIMIZATION)
@@ -160,17 +157,7 @@ def main():
     prof, K.CONV_PROFILE = K.CONV_PROFILE, None
     last_loss = float(loss)
     roofline_note = "HIP events around every launch of the kernel inside the timed region"
-    if model.use_graphs:
-        # kernels replayed from a HIP graph cannot carry per-launch events: time the same launches in 2 eager steps right after
-        model.use_graphs = False
-        K.CONV_PROFILE = []
-        for it in range(args.warmup + args.steps, args.warmup + args.steps + 2):
-            step(it)
-        torch.cuda.synchronize()
-        prof, K.CONV_PROFILE = K.CONV_PROFILE, None
-        model.use_graphs = True
-        roofline_note = "HIP events around every launch of the kernel in 2 eager (un-graphed) steps run right after the timed region"
-    prof_steps = 2 if model.use_graphs else args.steps
+    prof_steps = args.steps
     dt = D.max_over_ranks(dt, device)
 
     if rank == 0:
@@ -208,7 +195,7 @@ def main():
             "config": {"workload": "RadarDistill full training step (BASELINE configs[3]): frozen LiDAR teacher fwd + radar student "
                                    "fwd/bwd (VFE, SparseEnc, CMA+DCNv2, DenseEnc, CenterHead, AFD+PFD+detection losses) + clip + Adam",
                        "bev": f"{args.grid}x{args.grid}", "pillar_m": 0.2, "lidar_pts": 35000, "radar_pts": 2000, "boxes": 30,
-                       "hip_graphs": bool(args.graphs), "conv_math": args.math, "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "conv_math": args.math, "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "teacher_head": "computed (unused by the loss, as in the reference)", "final_loss": last_loss},
             "roofline": {"bound": "mfma", "kernel": "k_conv_igemm<128,128,2,2,false> (gathered implicit-GEMM conv: sparse + dense 3x3 / 1x1 / transposed, fp32 MFMA)",
                          "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -3,6 +3,7 @@ north_star asks).  Each Function's forward and backward run hand-written kernels
 owns the tensors and the graph.
 """
 import os
+import weakref
 
 import torch
 
@@ -27,25 +28,6 @@ def bump_weights_epoch():
     _WEIGHTS_EPOCH[0] += 1
 
 
-# > 0 while radardistill_amd.graphs is warming up / capturing a HIP graph.  Checked in addition to
-# torch.cuda.is_current_stream_capturing(): the captured BACKWARD runs on the autograd engine's thread, and anything that must
-# not leak eager-only state (per-step arena memory, cached weight layouts) into a graph has to see the capture from there too.
-_CAPTURE_DEPTH = [0]
-
-
-class capture_scope:
-    def __enter__(self):
-        _CAPTURE_DEPTH[0] += 1
-
-    def __exit__(self, *exc):
-        _CAPTURE_DEPTH[0] -= 1
-        return False
-
-
-def in_capture(device_is_cuda=True):
-    return _CAPTURE_DEPTH[0] > 0 or (device_is_cuda and torch.cuda.is_current_stream_capturing())
-
-
 class _ZeroArena:
     """Per-step pool of zero-initialised fp32 scratch (BatchNorm statistics, weight-gradient accumulators): ONE memset per
     step instead of one torch.zeros launch per layer.  `begin_step()` re-zeroes and rewinds; slices stay valid until the next
@@ -65,10 +47,6 @@ class _ZeroArena:
         self.off = 0
 
     def take(self, n, device):
-        if in_capture(device.type == "cuda"):
-            # inside a HIP-graph capture (forward OR the separately captured backward): the fill must be a node of that graph
-            # and the memory must belong to the graph's pool; the arena (re-zeroed outside the graph) is for eager code only
-            return torch.zeros(n, dtype=torch.float32, device=device)
         n_al = (n + 63) // 64 * 64
         if self.buf is None or self.buf.device != device or self.off + n_al > self.buf.numel():
             self.high = max(self.high, self.off + n_al)          # grow on the next step; this request falls back to a fresh tensor
@@ -81,40 +59,16 @@ class _ZeroArena:
 
 
 ARENA = _ZeroArena()
-_ARENA_STACK = []
 _CONST = {}
 
 
 def const_tensor(key, values, device, dtype=torch.float32):
-    """Small constant tensors (loss weights, safe boxes, channel->head maps) uploaded once: host->device copies are not
-    allowed inside a HIP-graph capture."""
+    """Small constant tensors (loss weights, safe boxes, channel->head maps) uploaded once instead of one host->device copy per step."""
     k = (key, str(device), dtype)
     t = _CONST.get(k)
     if t is None:
         t = _CONST[k] = torch.tensor(values, dtype=dtype, device=device)
     return t
-
-
-class private_arena:
-    """Route zero-scratch requests to a dedicated arena (a HIP-graph section owns its scratch and re-zeroes it inside the graph)."""
-
-    def __init__(self, arena, device):
-        self.arena, self.device = arena, device
-
-    def __enter__(self):
-        global ARENA
-        _ARENA_STACK.append((ARENA, list(_BN_TOUCHED)))
-        ARENA = self.arena
-        _BN_TOUCHED.clear()
-        self.arena.begin_step(self.device)
-        return self.arena
-
-    def __exit__(self, *exc):
-        global ARENA
-        end_forward()
-        ARENA, touched = _ARENA_STACK.pop()
-        _BN_TOUCHED.extend(touched)
-        return False
 
 
 _BN_TOUCHED = []          # BatchNorm modules that ran in train mode this step (num_batches_tracked bumped once, together)
@@ -141,22 +95,20 @@ def zeros_accum(n, device):
 
 
 def kernel_weight(param, Cout, Cin, taps, kind, flip=False):
-    """Parameter -> kernel layout [Cout][taps][Cin] (or its data-gradient transpose), cached per parameter version."""
+    """Parameter -> kernel layout [Cout][taps][Cin], cached per parameter version.  Frozen parameters (the teacher) only change
+    through torch (load_state_dict bumps `_version`); trainable ones also through the fused optimizer's raw pointers (epoch)."""
     src = param.detach()
     if not src.is_contiguous():
         src = src.contiguous()
     if kind == 0 and not flip:
         return src.reshape(Cout, taps, Cin)       # spconv layout [Cout,kh,kw,Cin] and nn.Linear [Cout,Cin] are already kernel layout
-    capturing = in_capture(param.is_cuda)
     key = (id(param), kind, flip)
-    ver = (param._version, _WEIGHTS_EPOCH[0], param.data_ptr())
-    if not capturing or not param.requires_grad:
-        hit = _LAYOUT_CACHE.get(key)
-        if hit is not None and hit[0] == ver:
-            return hit[1]
+    ver = (param._version, _WEIGHTS_EPOCH[0] if param.requires_grad else -1, param.data_ptr())
+    hit = _LAYOUT_CACHE.get(key)
+    if hit is not None and hit[0] == ver and hit[2]() is param:      # the weakref guards against id() reuse after a model is freed
+        return hit[1]
     w = K.weight_layout(src, Cout, Cin, taps, kind, flip)
-    if not capturing:                             # inside a HIP-graph capture the re-layout must be part of the graph (weights change between replays)
-        _LAYOUT_CACHE[key] = (ver, w)
+    _LAYOUT_CACHE[key] = (ver, w, weakref.ref(param))
     return w
 
 
@@ -305,15 +257,14 @@ def bn_eval_scale_shift(bn):
     unchanged (the frozen teacher: computed once instead of 4 small launches per layer per step)."""
     ver = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, _WEIGHTS_EPOCH[0] if bn.weight.requires_grad else -1,
            bn.weight.data_ptr(), bn.running_var.data_ptr())
-    capturing = in_capture(bn.weight.is_cuda) and bn.weight.requires_grad
     hit = _BN_FOLD_CACHE.get(id(bn))
-    if hit is not None and hit[0] == ver and not capturing:
+    if hit is not None and hit[0] == ver and hit[3]() is bn:
         return hit[1], hit[2]
     with torch.no_grad():
         rstd = torch.rsqrt(bn.running_var + bn.eps)
         scale = (bn.weight * rstd).contiguous()
         shift = (bn.bias - bn.running_mean * scale).contiguous()
-    _BN_FOLD_CACHE[id(bn)] = (ver, scale, shift)
+    _BN_FOLD_CACHE[id(bn)] = (ver, scale, shift, weakref.ref(bn))
     return scale, shift
 
 

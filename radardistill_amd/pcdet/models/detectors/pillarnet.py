@@ -21,24 +21,15 @@ class PillarNet(Detector3DTemplate):
         # The frozen teacher CenterHead's predictions (`lidar_pred_dicts`) are consumed by nothing in the distill loss
         # (pillarnet.py:65-73).  Kept on by default for fidelity; MODEL.SKIP_UNUSED_TEACHER_HEAD: True drops that dead work.
         self.skip_unused_teacher_head = bool(self.model_cfg.get('SKIP_UNUSED_TEACHER_HEAD', False))
-        # HIP-graph capture of the static-shape dense section (radardistill_amd/graphs.py); MODEL.HIP_GRAPHS or RD_HIP_GRAPHS=1
-        import os
-        self.use_graphs = bool(self.model_cfg.get('HIP_GRAPHS', False)) or os.environ.get('RD_HIP_GRAPHS', '0') == '1'
-        self._graphs = None
 
     def forward(self, batch_dict):
         from radardistill_amd import autograd as A
         dev = next(self.parameters()).device
         if dev.type == "cuda":
             A.begin_step(dev)
-        graphed = (self.use_graphs and self.training and dev.type == "cuda" and bool(self.model_cfg.get('DISTILL', None))
-                   and torch.is_grad_enabled() and all(getattr(self, n, None) is not None for n in
-                                                       ('backbone_2d', 'radar_backbone_2d', 'radar_dense_head')))
         prepared = False
         for cur_module in self.module_list:
             cur_name = cur_module.__class__.__name__
-            if graphed and cur_module in (self.backbone_2d, self.radar_backbone_2d, self.dense_head, self.radar_dense_head):
-                continue                               # the dense section runs as captured graphs below
             if not prepared and hasattr(cur_module, 'prepare'):
                 # Build the active-site pyramids (rulebooks) of BOTH branches now, while the stream only holds the cheap VFE
                 # kernels: their device->host count read-backs then never wait behind convolution work.
@@ -56,20 +47,6 @@ class PillarNet(Detector3DTemplate):
                 batch_dict = cur_module(batch_dict)
         if dev.type == "cuda":
             A.end_forward()
-        if graphed:
-            if self._graphs is None:
-                from radardistill_amd.graphs import DenseSectionGraphs
-                self._graphs = DenseSectionGraphs(self)
-            for n in ('backbone_2d', 'dense_head'):
-                m = getattr(self, n, None)
-                if m is not None and m.__class__.__name__ in self.no_grad_module:
-                    m.eval()
-            t = batch_dict['multi_scale_2d_features']
-            r = batch_dict['radar_multi_scale_2d_features']
-            loss, tb_dict, (l2d8, l2d) = self._graphs.run(r['x_conv4'], r['x_conv5'], t['x_conv4'], t['x_conv5'],
-                                                          batch_dict['gt_boxes'].float().contiguous())
-            batch_dict['spatial_features_2d_8x'], batch_dict['spatial_features_2d'] = l2d8, l2d
-            return {'loss': loss}, tb_dict, {}
         if self.training:
             if self.model_cfg.get('DISTILL', None) is None:
                 loss, tb_dict, disp_dict = self.get_training_loss()
