@@ -266,6 +266,23 @@ typedef struct {
 int rd_center_targets(const float *gt_boxes, int B, int M, int box_dim, const rd_target_cfg *cfg, float *heatmaps, float *target_boxes,
                       int64_t *inds, int64_t *masks, float *gt_box, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * L. Narrow-output 3x3 convolutions of all CenterHead branches in one launch (vector ALUs; stride 1, zero padding 1).
+ *    Replaces the per-branch final nn.Conv2d(64, n, 3, padding=1) of SeparateHead
+ *    (pcdet/models/dense_heads/radar_center_head.py:39-40,57-58; center_head.py:23-24,43-44), n = 1..4, for NB <= 64 branches.
+ *    y (B*H*W, ldy) channels-last rows holding every branch's 64 input channels at cin_off[b]; weight is the torch Conv2d layout
+ *    [NO][64][3][3] of the branches' weights concatenated on dim 0 (branch b owns rows col_off[b] .. col_off[b]+n_out[b]);
+ *    out / grad_out (B*H*W, NO).  cin_off / col_off / n_out are HOST arrays of NB ints (copied into the launch).
+ *    rd_nconv_dgrad writes the 64 channels of every branch of grad_y (rows, ldy) (other columns untouched);
+ *    rd_nconv_wgrad ACCUMULATES into grad_w [NO][64][3][3] (caller zero-fills).
+ * ---------------------------------------------------------------------------------------------- */
+int rd_nconv_fwd(const float *y, int ldy, const float *weight, const float *bias, int B, int H, int W, int NO, int NB,
+                 const int32_t *cin_off, const int32_t *col_off, const int32_t *n_out, float *out, void *stream);
+int rd_nconv_dgrad(const float *grad_out, const float *weight, int B, int H, int W, int NO, int NB, const int32_t *cin_off,
+                   const int32_t *col_off, const int32_t *n_out, float *grad_y, int ldy, void *stream);
+int rd_nconv_wgrad(const float *y, int ldy, const float *grad_out, int B, int H, int W, int NO, int NB, const int32_t *cin_off,
+                   const int32_t *col_off, const int32_t *n_out, float *grad_w, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

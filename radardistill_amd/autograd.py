@@ -102,6 +102,8 @@ def kernel_weight(param, Cout, Cin, taps, kind, flip=False):
         src = src.contiguous()
     if kind == 0 and not flip:
         return src.reshape(Cout, taps, Cin)       # spconv layout [Cout,kh,kw,Cin] and nn.Linear [Cout,Cin] are already kernel layout
+    if not param.is_leaf:                         # a per-step tensor (e.g. the concatenated head-branch weights): nothing to cache on
+        return K.weight_layout(src, Cout, Cin, taps, kind, flip)
     key = (id(param), kind, flip)
     ver = (param._version, _WEIGHTS_EPOCH[0] if param.requires_grad else -1, param.data_ptr())
     hit = _LAYOUT_CACHE.get(key)
@@ -161,6 +163,7 @@ class _ConvFn(torch.autograd.Function):
         out = K.conv_fwd(x, wk, spec.taps, bias, spec.out_rows, Cout, spec.fwd_ix, stats=stats, nbr_keepalive=spec.fwd_nbr)
         ctx.spec, ctx.Cout, ctx.Cin = spec, Cout, Cin
         ctx.has_bias = bias is not None
+        ctx.wk = wk                                # kernel-layout weights of THIS step (the optimizer runs after backward)
         ctx.save_for_backward(x, weight)
         return out
 
@@ -171,7 +174,7 @@ class _ConvFn(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            wk = kernel_weight(weight, Cout, Cin, spec.taps, spec.param_kind)
+            wk = ctx.wk
             go, Cp = grad_out, Cout
             if Cout % 32 != 0:      # narrow heads (1..3, 27 channels): zero-pad the contraction dim to the kernel's K step
                 Cp = (Cout + 31) // 32 * 32
@@ -247,6 +250,15 @@ def bn_act_train(x, bn, residual=None, act=1, stats=None):
         raise ValueError("Expected more than 1 value per channel when training")     # torch's own train-mode BN error
     _BN_TOUCHED.append(bn)
     return _BNActFn.apply(x, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, float(bn.eps), float(bn.momentum), act, stats)
+
+
+def bn_act_train_tensors(x, gamma, beta, running_mean, running_var, eps, momentum, act=1, stats=None, modules=()):
+    """Train-mode BatchNorm over explicit tensors (several BatchNorm modules batched on the channel axis); `modules` get their
+    num_batches_tracked bumped with everything else at end_forward()."""
+    if x.shape[0] <= 1:
+        raise ValueError("Expected more than 1 value per channel when training")
+    _BN_TOUCHED.extend(modules)
+    return _BNActFn.apply(x, gamma, beta, None, running_mean, running_var, eps, momentum, act, stats)
 
 
 _BN_FOLD_CACHE = {}
@@ -360,3 +372,32 @@ K_ = K
 
 def dwconv(x_rows, conv, B, H, W):
     return _DWConvFn.apply(x_rows, conv.weight, conv.bias, B, H, W)
+
+
+class _NConvFn(torch.autograd.Function):
+    """Final 3x3 convolutions (64 -> 1..4) of all CenterHead branches at once (nconv.hip)."""
+
+    @staticmethod
+    def forward(ctx, y, weight, bias, B, H, W, tab):
+        out = K.nconv_fwd(y, weight.detach().contiguous(), bias.detach().contiguous() if bias is not None else None, B, H, W, tab)
+        ctx.geom, ctx.tab, ctx.has_bias = (B, H, W), tab, bias is not None
+        ctx.save_for_backward(y, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        y, weight = ctx.saved_tensors
+        B, H, W = ctx.geom
+        go = go.contiguous()
+        gy = K.nconv_dgrad(go, weight.detach().contiguous(), B, H, W, ctx.tab, y.shape[1]) if ctx.needs_input_grad[0] else None
+        gw = K.nconv_wgrad(y, go, B, H, W, ctx.tab) if ctx.needs_input_grad[1] else None
+        gb = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = K.colsum(go) if go.shape[1] % 4 == 0 else go.sum(0)
+        return gy, gw, gb, None, None, None, None
+
+
+def nconv(y, weight, bias, B, H, W, tab):
+    if torch.is_grad_enabled() and (y.requires_grad or weight.requires_grad):
+        return _NConvFn.apply(y, weight, bias, B, H, W, tab)
+    return K.nconv_fwd(y, weight.detach().contiguous(), bias.detach().contiguous() if bias is not None else None, B, H, W, tab)

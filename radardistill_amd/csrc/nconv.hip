@@ -1,0 +1,289 @@
+// Narrow-output 3x3 convolutions of the CenterHead branches, all branches of all task heads in ONE launch.
+// See include/rdamd.h section L.
+//
+// SeparateHead (pcdet/models/dense_heads/radar_center_head.py:28-63) ends every branch with Conv2d(64 -> n, k3, p1), n = 1..3
+// (center 2, center_z 1, dim 3, rot 2, vel 2, iou 1, hm 1-2): 42 such convolutions per head module on nuScenes.  On the
+// matrix cores a 1..3-wide output wastes > 90 % of every 32-wide tile, so these run on the vector ALUs instead, straight from
+// the batched activation tensor y (rows, NB*64) that the batched first convolution + BatchNorm + ReLU of all branches produced:
+//
+//     out[p][col_b + n] = bias[col_b + n] + sum_t sum_c y[p + d_t][64 b + c] * w[col_b + n][c][t]
+//
+// Work split (all three kernels): grid = (B * ceil(H/8) row bands, NB branches), 256 threads; a block walks the 8x8 pixel
+// tiles of its band.  A thread owns 4 consecutive channels (lane & 15) of the pixels p = (tid >> 4) + 16 i of the tile, so the 16
+// lanes of a pixel read one contiguous 256-byte LDS row and weights / weight-gradient accumulators ([n][9 taps][4 channels])
+// live in registers for the whole band.  The 10x10x64 input halo of a tile is staged through LDS once (1.56x re-read from L2
+// instead of 9x).  HBM-bound: y is 352 MB at B = 8, 64x64 map, 42 branches.
+#include "common.hpp"
+
+using namespace rd;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NC_CB = 64;            // input channels per branch
+constexpr int NC_T = 8;              // output tile edge
+constexpr int NC_HALO = NC_T + 2;    // 10
+constexpr int NC_LDW = NC_CB + 4;    // LDS floats per halo pixel
+constexpr int NC_MAXB = 64;          // branches per launch
+constexpr int NC_MAXN = 4;           // outputs per branch
+
+struct NconvArgs {
+    const float *y;        // (rows, ldy)
+    int ldy;               // row stride of y / grad_y (floats)
+    const float *w;        // torch Conv2d layout [NO][64][3][3]
+    const float *bias;     // [NO] or null
+    const float *go;       // (rows, NO)
+    float *out;            // fwd: (rows, NO); dgrad: grad_y (rows, ldy); wgrad: grad_w [NO][64][9]
+    int NO, NB, B, H, W;
+    int cin_off[NC_MAXB];  // first channel of branch b in y
+    int col_off[NC_MAXB];  // first output column of branch b
+    int n_out[NC_MAXB];    // outputs of branch b (1..4)
+};
+
+__device__ __forceinline__ float reduce16(float v) {
+    v += __shfl_xor(v, 8, 16);
+    v += __shfl_xor(v, 4, 16);
+    v += __shfl_xor(v, 2, 16);
+    v += __shfl_xor(v, 1, 16);
+    return v;
+}
+
+// stage the 10x10 halo (all 64 channels of branch `cin0`) of tile (y0, x0) of image b
+__device__ __forceinline__ void load_halo(const NconvArgs &a, int b, int y0, int x0, int cin0, float *lds) {
+    for (int i = threadIdx.x; i < NC_HALO * NC_HALO * (NC_CB / 4); i += 256) {
+        const int hp = i >> 4, q = i & 15;
+        const int gy = y0 - 1 + hp / NC_HALO, gx = x0 - 1 + hp % NC_HALO;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+            v = *reinterpret_cast<const f32x4 *>(a.y + ((int64_t)(b * a.H + gy) * a.W + gx) * a.ldy + cin0 + 4 * q);
+        *reinterpret_cast<f32x4 *>(lds + hp * NC_LDW + 4 * q) = v;
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void load_weights(const NconvArgs &a, int col0, int l16, float (&w)[N][9][4]) {
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) w[n][t][j] = a.w[((int64_t)(col0 + n) * NC_CB + 4 * l16 + j) * 9 + t];
+}
+
+template <int N>
+__device__ __forceinline__ void nconv_fwd_body(const NconvArgs &a, float *lds) {
+    const int br = blockIdx.y, col0 = a.col_off[br], cin0 = a.cin_off[br];
+    const int bands = (a.H + NC_T - 1) / NC_T;
+    const int b = blockIdx.x / bands, y0 = (blockIdx.x % bands) * NC_T;
+    const int l16 = threadIdx.x & 15, pg = threadIdx.x >> 4;
+    float w[N][9][4];
+    load_weights<N>(a, col0, l16, w);
+    float bias[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) bias[n] = a.bias ? a.bias[col0 + n] : 0.f;
+    for (int x0 = 0; x0 < a.W; x0 += NC_T) {
+        load_halo(a, b, y0, x0, cin0, lds);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = pg + 16 * i, py = p >> 3, px = p & 7;
+            float acc[N];
+#pragma unroll
+            for (int n = 0; n < N; ++n) acc[n] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const f32x4 x = *reinterpret_cast<const f32x4 *>(lds + ((py + t / 3) * NC_HALO + px + t % 3) * NC_LDW + 4 * l16);
+#pragma unroll
+                for (int n = 0; n < N; ++n)
+                    acc[n] += x[0] * w[n][t][0] + x[1] * w[n][t][1] + x[2] * w[n][t][2] + x[3] * w[n][t][3];
+            }
+#pragma unroll
+            for (int n = 0; n < N; ++n) acc[n] = reduce16(acc[n]);
+            const int gy = y0 + py, gx = x0 + px;
+            if (l16 == 0 && gy < a.H && gx < a.W) {
+                float *o = a.out + ((int64_t)(b * a.H + gy) * a.W + gx) * a.NO + col0;
+#pragma unroll
+                for (int n = 0; n < N; ++n) o[n] = acc[n] + bias[n];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nconv_fwd(const NconvArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[NC_HALO * NC_HALO * NC_LDW];
+    switch (a.n_out[blockIdx.y]) {  // block-uniform
+        case 1: nconv_fwd_body<1>(a, lds); break;
+        case 2: nconv_fwd_body<2>(a, lds); break;
+        case 3: nconv_fwd_body<3>(a, lds); break;
+        default: nconv_fwd_body<4>(a, lds); break;
+    }
+}
+
+// grad_y[q][cin0 + c] = sum_t sum_n go[q - d_t][col0 + n] * w[col0 + n][c][t],  d_t = (t/3 - 1, t%3 - 1)
+template <int N>
+__device__ __forceinline__ void nconv_dgrad_body(const NconvArgs &a, float *lds) {
+    const int br = blockIdx.y, col0 = a.col_off[br], cin0 = a.cin_off[br];
+    const int bands = (a.H + NC_T - 1) / NC_T;
+    const int b = blockIdx.x / bands, y0 = (blockIdx.x % bands) * NC_T;
+    const int l16 = threadIdx.x & 15, pg = threadIdx.x >> 4;
+    float w[N][9][4];
+    load_weights<N>(a, col0, l16, w);
+    for (int x0 = 0; x0 < a.W; x0 += NC_T) {
+        // halo of grad_out: 10x10 pixels x N values
+        for (int i = threadIdx.x; i < NC_HALO * NC_HALO * N; i += 256) {
+            const int hp = i / N, n = i % N;
+            const int gy = y0 - 1 + hp / NC_HALO, gx = x0 - 1 + hp % NC_HALO;
+            float v = 0.f;
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = a.go[((int64_t)(b * a.H + gy) * a.W + gx) * a.NO + col0 + n];
+            lds[hp * NC_MAXN + n] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = pg + 16 * i, py = p >> 3, px = p & 7;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float *g = lds + ((py + 2 - t / 3) * NC_HALO + px + 2 - t % 3) * NC_MAXN;
+#pragma unroll
+                for (int n = 0; n < N; ++n) {
+                    const float gv = g[n];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] += gv * w[n][t][j];
+                }
+            }
+            const int gy = y0 + py, gx = x0 + px;
+            if (gy < a.H && gx < a.W)
+                *reinterpret_cast<f32x4 *>(a.out + ((int64_t)(b * a.H + gy) * a.W + gx) * a.ldy + cin0 + 4 * l16) = acc;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nconv_dgrad(const NconvArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[NC_HALO * NC_HALO * NC_MAXN];
+    switch (a.n_out[blockIdx.y]) {
+        case 1: nconv_dgrad_body<1>(a, lds); break;
+        case 2: nconv_dgrad_body<2>(a, lds); break;
+        case 3: nconv_dgrad_body<3>(a, lds); break;
+        default: nconv_dgrad_body<4>(a, lds); break;
+    }
+}
+
+// grad_w[col0 + n][c][t] += sum_p go[p][col0 + n] * y[p + d_t][cin0 + c]   (fp32 atomics combine the bands)
+template <int N>
+__device__ __forceinline__ void nconv_wgrad_body(const NconvArgs &a, float *lds, float *g_l, float *red) {
+    const int br = blockIdx.y, col0 = a.col_off[br], cin0 = a.cin_off[br];
+    const int bands = (a.H + NC_T - 1) / NC_T;
+    const int b = blockIdx.x / bands, y0 = (blockIdx.x % bands) * NC_T;
+    const int l16 = threadIdx.x & 15, pg = threadIdx.x >> 4;
+    float acc[N][9][4];
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[n][t][j] = 0.f;
+    for (int x0 = 0; x0 < a.W; x0 += NC_T) {
+        load_halo(a, b, y0, x0, cin0, lds);
+        for (int i = threadIdx.x; i < NC_T * NC_T * N; i += 256) {
+            const int p = i / N, n = i % N;
+            const int gy = y0 + (p >> 3), gx = x0 + (p & 7);
+            g_l[p * NC_MAXN + n] = (gy < a.H && gx < a.W) ? a.go[((int64_t)(b * a.H + gy) * a.W + gx) * a.NO + col0 + n] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = pg + 16 * i, py = p >> 3, px = p & 7;
+            float g[N];
+#pragma unroll
+            for (int n = 0; n < N; ++n) g[n] = g_l[p * NC_MAXN + n];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const f32x4 x = *reinterpret_cast<const f32x4 *>(lds + ((py + t / 3) * NC_HALO + px + t % 3) * NC_LDW + 4 * l16);
+#pragma unroll
+                for (int n = 0; n < N; ++n)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[n][t][j] += g[n] * x[j];
+            }
+        }
+        __syncthreads();
+    }
+    // combine the 16 pixel groups in LDS ([n][c][t], the output layout), then one global atomic per element
+    for (int i = threadIdx.x; i < N * NC_CB * 9; i += 256) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(&red[(n * NC_CB + 4 * l16 + j) * 9 + t], acc[n][t][j]);
+    __syncthreads();
+    for (int i = threadIdx.x; i < N * NC_CB * 9; i += 256) {
+        const float v = red[i];
+        if (v != 0.f) atomicAdd(&a.out[(int64_t)col0 * NC_CB * 9 + i], v);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nconv_wgrad(const NconvArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[NC_HALO * NC_HALO * NC_LDW];
+    __shared__ float g_l[NC_T * NC_T * NC_MAXN];
+    __shared__ float red[NC_MAXN * NC_CB * 9];
+    switch (a.n_out[blockIdx.y]) {
+        case 1: nconv_wgrad_body<1>(a, lds, g_l, red); break;
+        case 2: nconv_wgrad_body<2>(a, lds, g_l, red); break;
+        case 3: nconv_wgrad_body<3>(a, lds, g_l, red); break;
+        default: nconv_wgrad_body<4>(a, lds, g_l, red); break;
+    }
+}
+
+static int fill_args(NconvArgs &a, const char *who, int B, int H, int W, int ldy, int NO, int NB, const int32_t *cin_off, const int32_t *col_off,
+                     const int32_t *n_out) {
+    RD_REQUIRE(B > 0 && H > 0 && W > 0, "%s: bad geometry", who);
+    RD_REQUIRE(NB >= 1 && NB <= NC_MAXB, "%s: %d branches outside 1..%d", who, NB, NC_MAXB);
+    RD_REQUIRE(cin_off && col_off && n_out, "%s: branch tables are NULL", who);
+    RD_REQUIRE(ldy % 4 == 0, "%s: ldy=%d must be a multiple of 4", who, ldy);
+    for (int b = 0; b < NB; ++b) {
+        RD_REQUIRE(n_out[b] >= 1 && n_out[b] <= NC_MAXN, "%s: branch %d has %d outputs (1..%d)", who, b, n_out[b], NC_MAXN);
+        RD_REQUIRE(col_off[b] >= 0 && col_off[b] + n_out[b] <= NO, "%s: branch %d columns outside [0,%d)", who, b, NO);
+        RD_REQUIRE(cin_off[b] >= 0 && cin_off[b] % 4 == 0 && cin_off[b] + NC_CB <= ldy, "%s: branch %d channels outside the row", who, b);
+        a.cin_off[b] = cin_off[b];
+        a.col_off[b] = col_off[b];
+        a.n_out[b] = n_out[b];
+    }
+    a.ldy = ldy; a.NO = NO; a.NB = NB; a.B = B; a.H = H; a.W = W;
+    return RD_OK;
+}
+
+extern "C" int rd_nconv_fwd(const float *y, int ldy, const float *weight, const float *bias, int B, int H, int W, int NO, int NB,
+                            const int32_t *cin_off, const int32_t *col_off, const int32_t *n_out, float *out, void *stream) {
+    NconvArgs a{};
+    int rc = fill_args(a, "rd_nconv_fwd", B, H, W, ldy, NO, NB, cin_off, col_off, n_out);
+    if (rc) return rc;
+    a.y = y; a.w = weight; a.bias = bias; a.out = out;
+    dim3 grid((unsigned)(B * cdiv(H, NC_T)), (unsigned)NB);
+    k_nconv_fwd<<<grid, 256, 0, S(stream)>>>(a);
+    return check_launch("rd_nconv_fwd");
+}
+
+extern "C" int rd_nconv_dgrad(const float *grad_out, const float *weight, int B, int H, int W, int NO, int NB, const int32_t *cin_off,
+                              const int32_t *col_off, const int32_t *n_out, float *grad_y, int ldy, void *stream) {
+    NconvArgs a{};
+    int rc = fill_args(a, "rd_nconv_dgrad", B, H, W, ldy, NO, NB, cin_off, col_off, n_out);
+    if (rc) return rc;
+    a.go = grad_out; a.w = weight; a.out = grad_y;
+    dim3 grid((unsigned)(B * cdiv(H, NC_T)), (unsigned)NB);
+    k_nconv_dgrad<<<grid, 256, 0, S(stream)>>>(a);
+    return check_launch("rd_nconv_dgrad");
+}
+
+extern "C" int rd_nconv_wgrad(const float *y, int ldy, const float *grad_out, int B, int H, int W, int NO, int NB, const int32_t *cin_off,
+                              const int32_t *col_off, const int32_t *n_out, float *grad_w, void *stream) {
+    NconvArgs a{};
+    int rc = fill_args(a, "rd_nconv_wgrad", B, H, W, ldy, NO, NB, cin_off, col_off, n_out);
+    if (rc) return rc;
+    a.y = y; a.go = grad_out; a.out = grad_w;
+    dim3 grid((unsigned)(B * cdiv(H, NC_T)), (unsigned)NB);
+    k_nconv_wgrad<<<grid, 256, 0, S(stream)>>>(a);
+    return check_launch("rd_nconv_wgrad");
+}

@@ -18,40 +18,45 @@ __device__ __forceinline__ float gelu_grad(float z) {
     return cdf + z * pdf;
 }
 
-// Generic column reduction: F(row, c) -> (v1, v2) per element; partial[block][2][C].
+// Generic column reduction: F(row, c) -> (v1, v2) per element; partial[block x][2][C].  Columns are split into chunks of
+// RED_CHUNK (grid.y), so any C % 4 == 0 works (the batched CenterHead BatchNorm has C = 2688).
+constexpr int RED_CHUNK = 512;
+
 template <class F>
 __global__ __launch_bounds__(256) void k_colreduce(int64_t rows, int C, F f, float *partial) {
-    extern __shared__ float sm[];  // [groups][2][C] staged reduction
-    const int tpr = C / 4;               // threads per row
-    const int groups = 256 / tpr > 0 ? 256 / tpr : 1;
+    extern __shared__ float sm[];  // [groups][2][cw] staged reduction
+    const int col0 = blockIdx.y * RED_CHUNK;
+    const int cw = min(RED_CHUNK, C - col0);
+    const int tpr = cw / 4;              // threads per row (<= 128)
+    const int groups = 256 / tpr;
     const int tid = threadIdx.x;
-    if (tpr <= 256) {
-        const int g = tid / tpr, c4 = (tid % tpr) * 4;
-        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-        if (g < groups) {
-            for (int64_t r = (int64_t)blockIdx.x * groups + g; r < rows; r += (int64_t)gridDim.x * groups) {
-                f32x4 a, b;
-                f(r, c4, a, b);
-                s1 += a;
-                s2 += b;
-            }
-            float *dst = sm + (int64_t)g * 2 * C;
-            *reinterpret_cast<f32x4 *>(dst + c4) = s1;
-            *reinterpret_cast<f32x4 *>(dst + C + c4) = s2;
+    const int g = tid / tpr, c4 = (tid % tpr) * 4;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    if (g < groups) {
+        for (int64_t r = (int64_t)blockIdx.x * groups + g; r < rows; r += (int64_t)gridDim.x * groups) {
+            f32x4 a, b;
+            f(r, col0 + c4, a, b);
+            s1 += a;
+            s2 += b;
         }
-        __syncthreads();
-        for (int i = tid; i < 2 * C; i += 256) {
-            float s = 0.f;
-            for (int q = 0; q < groups; ++q) s += sm[(int64_t)q * 2 * C + i];
-            partial[(int64_t)blockIdx.x * 2 * C + i] = s;
-        }
+        float *dst = sm + (int64_t)g * 2 * cw;
+        *reinterpret_cast<f32x4 *>(dst + c4) = s1;
+        *reinterpret_cast<f32x4 *>(dst + cw + c4) = s2;
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * cw; i += 256) {
+        float s = 0.f;
+        for (int q = 0; q < groups; ++q) s += sm[(int64_t)q * 2 * cw + i];
+        const int which = i / cw, c = i % cw;
+        partial[((int64_t)blockIdx.x * 2 + which) * C + col0 + c] = s;
     }
 }
 
 // Final stage: 32 columns per block; 8 row-groups of threads walk the per-block partials with coalesced 128-byte reads, sum in
-// double in a fixed order (deterministic), then combine through LDS.
-__global__ __launch_bounds__(256) void k_colreduce_final(const float *__restrict__ partial, int n_blocks, int C2, float *out) {
+// double in a fixed order (deterministic), then combine through LDS.  Columns [0, C) go to out1, [C, 2C) to out2 (may be null).
+__global__ __launch_bounds__(256) void k_colreduce_final(const float *__restrict__ partial, int n_blocks, int C, float *out1, float *out2) {
     __shared__ double red[8][32];
+    const int C2 = 2 * C;
     const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
     const int col = blockIdx.x * 32 + c;
     double s = 0.0;
@@ -63,20 +68,22 @@ __global__ __launch_bounds__(256) void k_colreduce_final(const float *__restrict
         double t = 0.0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += red[k][c];
-        out[col] = (float)t;
+        if (col < C) out1[col] = (float)t;
+        else if (out2) out2[col - C] = (float)t;
     }
 }
 
 template <class F>
-static int colreduce(int64_t rows, int C, F f, float *out2C, float *ws, int64_t ws_bytes, hipStream_t st, const char *who) {
-    RD_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "%s: C=%d must be a multiple of 4 in [4,1024]", who, C);
-    const int tpr = C / 4, groups = 256 / tpr;
+static int colreduce(int64_t rows, int C, F f, float *out1, float *out2, float *ws, int64_t ws_bytes, hipStream_t st, const char *who) {
+    RD_REQUIRE(C % 4 == 0 && C >= 4, "%s: C=%d must be a positive multiple of 4", who, C);
+    const int cw = std::min(C, RED_CHUNK), tpr = cw / 4, groups = 256 / tpr;
+    const int chunks = (int)cdiv(C, RED_CHUNK);
     int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(RED_MAX_BLOCKS, cdiv(rows, (int64_t)groups * 8)));
     RD_REQUIRE(ws_bytes >= (int64_t)blocks * 2 * C * 4, "%s: workspace too small (%lld < %lld)", who, (long long)ws_bytes,
                (long long)blocks * 2 * C * 4);
-    size_t shm = (size_t)groups * 2 * C * 4;
-    k_colreduce<F><<<blocks, 256, shm, st>>>(rows, C, f, ws);
-    k_colreduce_final<<<cdiv(2 * C, 32), 256, 0, st>>>(ws, blocks, 2 * C, out2C);
+    size_t shm = (size_t)groups * 2 * cw * 4;
+    k_colreduce<F><<<dim3(blocks, chunks), 256, shm, st>>>(rows, C, f, ws);
+    k_colreduce_final<<<cdiv(out2 ? 2 * C : C, 32), 256, 0, st>>>(ws, blocks, C, out1, out2);
     return check_launch(who);
 }
 
@@ -96,7 +103,7 @@ extern "C" int rd_bn_stats(const float *x, int64_t rows, int C, float *stats, fl
         RD_HIP(hipMemsetAsync(stats, 0, (size_t)2 * C * 4, S(stream)));
         return RD_OK;
     }
-    return colreduce(rows, C, StatsF{x, C}, stats, ws, ws_bytes, S(stream), "rd_bn_stats");
+    return colreduce(rows, C, StatsF{x, C}, stats, stats + C, ws, ws_bytes, S(stream), "rd_bn_stats");
 }
 
 struct ColsumF {
@@ -107,23 +114,13 @@ struct ColsumF {
         b = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 };
-__global__ void k_copy(const float *src, float *dst, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = src[i];
-}
-
 extern "C" int rd_colsum(const float *x, int64_t rows, int C, float *out, float *ws, int64_t ws_bytes, void *stream) {
     hipStream_t st = S(stream);
     if (rows <= 0) {
         RD_HIP(hipMemsetAsync(out, 0, (size_t)C * 4, st));
         return RD_OK;
     }
-    // ws layout: [2C result][partials]
-    RD_REQUIRE(ws_bytes >= (int64_t)2 * C * 4, "rd_colsum: workspace too small");
-    int rc = colreduce(rows, C, ColsumF{x, C}, ws, ws + 2 * C, ws_bytes - 2 * C * 4, st, "rd_colsum");
-    if (rc) return rc;
-    k_copy<<<cdiv(C, 256), 256, 0, st>>>(ws, out, C);
-    return check_launch("rd_colsum");
+    return colreduce(rows, C, ColsumF{x, C}, out, nullptr, ws, ws_bytes, st, "rd_colsum");
 }
 
 __global__ void k_bn_finalize(const float *stats, float n, int C, const float *gamma, const float *beta, float eps, float momentum,
@@ -208,8 +205,8 @@ struct BnBwdF {
 
 __global__ void k_bn_bwd_apply(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ gy, int64_t n4, int C,
                                const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ rstd,
-                               const float *__restrict__ scale, const float *__restrict__ shift, int act, const float *__restrict__ sums,
-                               float inv_n, float *__restrict__ gx, float *__restrict__ gres) {
+                               const float *__restrict__ scale, const float *__restrict__ shift, int act, const float *__restrict__ sum_g,
+                               const float *__restrict__ sum_gx, float inv_n, float *__restrict__ gx, float *__restrict__ gres) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         int c = (int)((i * 4) % C);
         f32x4 g = reinterpret_cast<const f32x4 *>(gy)[i];
@@ -225,17 +222,10 @@ __global__ void k_bn_bwd_apply(const float *__restrict__ x, const float *__restr
         for (int k = 0; k < 4; ++k) {
             float xh = (xv[k] - mean[c + k]) * rstd[c + k];
             float ga = gamma ? gamma[c + k] : 1.f;
-            o[k] = ga * rstd[c + k] * (g[k] - sums[c + k] * inv_n - xh * sums[C + c + k] * inv_n);
+            o[k] = ga * rstd[c + k] * (g[k] - sum_g[c + k] * inv_n - xh * sum_gx[c + k] * inv_n);
         }
         reinterpret_cast<f32x4 *>(gx)[i] = o;
     }
-}
-
-__global__ void k_split2(const float *sums, int C, float *gbeta, float *ggamma) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    if (gbeta) gbeta[c] = sums[c];
-    if (ggamma) ggamma[c] = sums[C + c];
 }
 
 extern "C" int rd_bn_bwd(const float *x, const float *y, const float *grad_y, int64_t rows, int C, const float *gamma, const float *mean,
@@ -246,14 +236,13 @@ extern "C" int rd_bn_bwd(const float *x, const float *y, const float *grad_y, in
     RD_REQUIRE(!(act == 2 && has_residual), "rd_bn_bwd: gelu with residual is not supported");
     RD_REQUIRE(ws_bytes >= rd_bn_bwd_ws_bytes(rows, C), "rd_bn_bwd: workspace too small");
     hipStream_t st = S(stream);
-    float *sums = ws;  // [2C]: dbeta, dgamma
-    int rc = colreduce(rows, C, BnBwdF{x, y, grad_y, mean, rstd, scale, shift, C, act}, sums, ws + 2 * C, ws_bytes - 2 * C * 4, st, "rd_bn_bwd");
+    RD_REQUIRE(grad_gamma && grad_beta, "rd_bn_bwd: grad_gamma / grad_beta are required (the apply kernel reads them)");
+    int rc = colreduce(rows, C, BnBwdF{x, y, grad_y, mean, rstd, scale, shift, C, act}, grad_beta, grad_gamma, ws, ws_bytes, st, "rd_bn_bwd");
     if (rc) return rc;
     int64_t n4 = rows * C / 4;
     int blocks = (int)std::min<int64_t>(cdiv(n4, 256), 4096);
-    k_bn_bwd_apply<<<blocks, 256, 0, st>>>(x, y, grad_y, n4, C, gamma, mean, rstd, scale, shift, act, sums, 1.0f / (float)rows, grad_x,
-                                           has_residual ? grad_res : nullptr);
-    k_split2<<<cdiv(C, 256), 256, 0, st>>>(sums, C, grad_beta, grad_gamma);
+    k_bn_bwd_apply<<<blocks, 256, 0, st>>>(x, y, grad_y, n4, C, gamma, mean, rstd, scale, shift, act, grad_beta, grad_gamma, 1.0f / (float)rows,
+                                           grad_x, has_residual ? grad_res : nullptr);
     return check_launch("rd_bn_bwd");
 }
 

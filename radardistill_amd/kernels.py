@@ -441,6 +441,65 @@ def center_targets(gt_boxes, cfg_struct):
     return {"heatmaps": hm, "target_boxes": tb, "inds": inds, "masks": masks, "gt_box": gb}
 
 
+# ------------------------------------------------------------------------------------------ narrow convs of the head branches
+class BranchTable:
+    """Host-side (cin_off, col_off, n_out) tables of rd_nconv_* as ctypes int arrays (built once per head module)."""
+
+    def __init__(self, cin_off, col_off, n_out):
+        n = len(n_out)
+        if not (len(cin_off) == len(col_off) == n and 1 <= n <= 64):
+            raise RuntimeError("BranchTable: 1..64 branches, equal-length tables")
+        arr = ctypes.c_int32 * n
+        self.nb = n
+        self.cin, self.col, self.n = arr(*cin_off), arr(*col_off), arr(*n_out)
+        self.no = max(c + k for c, k in zip(col_off, n_out))
+        self.cin_max = max(cin_off) + 64
+
+
+def _nconv_chk(y, B, H, W, tab, who):
+    _chk(y, f32, who, 2)
+    if y.shape[0] != B * H * W or y.shape[1] < tab.cin_max or y.shape[1] % 4:
+        raise RuntimeError(f"{who}: shape {tuple(y.shape)} does not hold {tab.nb} branches of 64 channels over {B}x{H}x{W} pixels")
+
+
+def nconv_fwd(y, weight, bias, B, H, W, tab):
+    """y (B*H*W, NB*64) -> (B*H*W, NO); weight (NO, 64, 3, 3) torch layout, bias (NO,) or None."""
+    _nconv_chk(y, B, H, W, tab, "nconv input")
+    _chk(weight, f32, "nconv weight")
+    if tuple(weight.shape) != (tab.no, 64, 3, 3) or (bias is not None and _chk(bias, f32, "nconv bias").numel() != tab.no):
+        raise RuntimeError(f"nconv: weight {tuple(weight.shape)} / bias do not match {tab.no} output columns")
+    out = torch.empty((y.shape[0], tab.no), dtype=f32, device=y.device)
+    check(native.lib().rd_nconv_fwd(_p(y), y.shape[1], _p(weight), _p(bias), B, H, W, tab.no, tab.nb, tab.cin, tab.col, tab.n, _p(out),
+                                    _stream()), "rd_nconv_fwd")
+    return out
+
+
+def nconv_dgrad(grad_out, weight, B, H, W, tab, ldy):
+    _chk(grad_out, f32, "nconv grad_out", 2)
+    if grad_out.shape != (B * H * W, tab.no) or tuple(weight.shape) != (tab.no, 64, 3, 3) or ldy < tab.cin_max:
+        raise RuntimeError("nconv_dgrad: shape mismatch")
+    # every column of grad_y must be owned by a branch (the kernel writes only those): true when the branches tile the row
+    if ldy != tab.nb * 64:
+        gy = torch.zeros((grad_out.shape[0], ldy), dtype=f32, device=grad_out.device)
+    else:
+        gy = torch.empty((grad_out.shape[0], ldy), dtype=f32, device=grad_out.device)
+    check(native.lib().rd_nconv_dgrad(_p(grad_out), _p(_chk(weight, f32, "nconv weight")), B, H, W, tab.no, tab.nb, tab.cin, tab.col, tab.n,
+                                      _p(gy), ldy, _stream()), "rd_nconv_dgrad")
+    return gy
+
+
+def nconv_wgrad(y, grad_out, B, H, W, tab):
+    _nconv_chk(y, B, H, W, tab, "nconv input")
+    _chk(grad_out, f32, "nconv grad_out", 2)
+    if grad_out.shape != (B * H * W, tab.no):
+        raise RuntimeError("nconv_wgrad: grad_out shape mismatch")
+    from . import autograd as _A
+    gw = _A.zeros_accum(tab.no * 576, y.device).view(tab.no, 64, 3, 3)
+    check(native.lib().rd_nconv_wgrad(_p(y), y.shape[1], _p(grad_out), B, H, W, tab.no, tab.nb, tab.cin, tab.col, tab.n, _p(gw), _stream()),
+          "rd_nconv_wgrad")
+    return gw
+
+
 # ------------------------------------------------------------------------------------------ arithmetic mode of the conv kernels
 def set_conv_math(mode):
     """'f32': exact fp32 MFMA (default).  'bf16x3': split-bf16 MFMA, ~4e-6 relative error (conv_b3.hip)."""

@@ -61,6 +61,110 @@ class SeparateHead(nn.Module):
         return ret_dict
 
 
+class _BranchBatch:
+    """Execution plan that runs every branch of every SeparateHead of one CenterHead together (MI355X-first; the module tree and
+    state_dict stay the reference's): the 42 first convolutions (64->64) as ONE implicit-GEMM conv with Cout = 42*64 and ONE
+    BatchNorm+ReLU over those channels, the 42 final convolutions (64 -> 1..3) as ONE vector-ALU launch (nconv.hip).
+    Output columns are grouped [hm | center | center_z | dim | rot | vel | iou], heads inner, so the batched loss reads the
+    stacked maps as views.  `build` returns None when a head does not have the standard two-stage 64-channel branches."""
+
+    @staticmethod
+    def build(head):
+        from radardistill_amd import kernels as K
+        names = list(head.heads_list[0].sep_head_dict.keys())
+        group_names = (['hm'] if 'hm' in names else []) + [n for n in names if n != 'hm']
+        branches, groups, col = [], {}, 0
+        for name in group_names:
+            c0 = col
+            widths = []
+            for h, sh in enumerate(head.heads_list):
+                if list(sh.sep_head_dict.keys()) != names:
+                    return None
+                fc = getattr(sh, name)
+                if len(fc) != 2 or not isinstance(fc[0], nn.Sequential) or not isinstance(fc[1], nn.Conv2d):
+                    return None
+                c1, bn, c2 = fc[0][0], fc[0][1], fc[1]
+                ok = (isinstance(c1, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d) and c1.in_channels == 64 and c1.out_channels == 64
+                      and c2.in_channels == 64 and 1 <= c2.out_channels <= 4 and c2.bias is not None
+                      and all(c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1) and c.groups == 1
+                              for c in (c1, c2)))
+                if not ok:
+                    return None
+                branches.append((h, name, c1, bn, c2, col))
+                widths.append(c2.out_channels)
+                col += c2.out_channels
+            groups[name] = (c0, widths)
+        if not branches or len(branches) > 64:
+            return None
+        bn0 = branches[0][3]
+        if any(b[3].eps != bn0.eps or b[3].momentum != bn0.momentum or (b[2].bias is None) != (branches[0][2].bias is None) for b in branches):
+            return None
+        plan = _BranchBatch()
+        plan.branches, plan.groups, plan.names, plan.n_heads, plan.no = branches, groups, names, len(head.heads_list), col
+        plan.tab = K.BranchTable([64 * i for i in range(len(branches))], [b[5] for b in branches], [b[4].out_channels for b in branches])
+        plan.frozen_cache = None
+        return plan
+
+    def _frozen_tensors(self):
+        """Teacher: concatenated kernel-layout weights and folded BatchNorm, rebuilt only when a source tensor changes."""
+        from radardistill_amd import kernels as K
+        src = [t for (_, _, c1, bn, c2, _) in self.branches for t in (c1.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, c2.weight, c2.bias)]
+        ver = (tuple(t._version for t in src), src[0].data_ptr())
+        if self.frozen_cache is None or self.frozen_cache[0] != ver:
+            with torch.no_grad():
+                w1 = torch.cat([b[2].weight for b in self.branches], 0).contiguous()
+                w1k = K.weight_layout(w1, w1.shape[0], 64, 9, 1)
+                b1 = torch.cat([b[2].bias for b in self.branches]) if self.branches[0][2].bias is not None else None
+                rstd = torch.rsqrt(torch.cat([b[3].running_var for b in self.branches]) + self.branches[0][3].eps)
+                scale = (torch.cat([b[3].weight for b in self.branches]) * rstd).contiguous()
+                shift = (torch.cat([b[3].bias for b in self.branches]) - torch.cat([b[3].running_mean for b in self.branches]) * scale).contiguous()
+                w2 = torch.cat([b[4].weight for b in self.branches], 0).contiguous()
+                b2 = torch.cat([b[4].bias for b in self.branches]).contiguous()
+            self.frozen_cache = (ver, w1k, b1, scale, shift, w2, b2)
+        return self.frozen_cache[1:]
+
+    def run(self, x):
+        """x = (rows (B*H*W, 64), B, H, W) -> (out (B*H*W, NO), per-head dicts of NCHW views)."""
+        from radardistill_amd import kernels as K
+        rows, B, H, W = x
+        C1 = 64 * len(self.branches)
+        spec = A.dense_conv_spec(B, H, W, 3, 3, 1, 1)
+        bns = [b[3] for b in self.branches]
+        training = bns[0].training
+        if any(bn.training != training for bn in bns):
+            return None
+        params_frozen = not any(p.requires_grad for b in self.branches for m in b[2:5] for p in m.parameters())
+        if (not torch.is_grad_enabled() or (params_frozen and not rows.requires_grad)) and not training:
+            w1k, b1, scale, shift, w2, b2 = self._frozen_tensors()
+            y = K.conv_fwd(rows, w1k, 9, b1, rows.shape[0], C1, spec.fwd_ix, scale=scale, shift=shift, relu=True)
+            out = K.nconv_fwd(y, w2, b2, B, H, W, self.tab)
+        elif training:
+            w1 = torch.cat([b[2].weight for b in self.branches], 0)
+            b1 = torch.cat([b[2].bias for b in self.branches]) if self.branches[0][2].bias is not None else None
+            stats = A.zeros_stats(2 * C1, rows.device)
+            raw = A.conv(rows, w1, b1, spec, C1, stats)
+            gamma = torch.cat([bn.weight for bn in bns])
+            beta = torch.cat([bn.bias for bn in bns])
+            with torch.no_grad():
+                rm = torch.cat([bn.running_mean for bn in bns])
+                rv = torch.cat([bn.running_var for bn in bns])
+            y = A.bn_act_train_tensors(raw, gamma, beta, rm, rv, float(bns[0].eps), float(bns[0].momentum), act=1, stats=stats, modules=bns)
+            with torch.no_grad():
+                torch._foreach_copy_([bn.running_mean for bn in bns], list(rm.split(64)))
+                torch._foreach_copy_([bn.running_var for bn in bns], list(rv.split(64)))
+            w2 = torch.cat([b[4].weight for b in self.branches], 0)
+            b2 = torch.cat([b[4].bias for b in self.branches])
+            out = A.nconv(y, w2, b2, B, H, W, self.tab)
+        else:
+            return None                       # eval-mode BatchNorm with gradients: rare, the per-branch path handles it
+        o4 = out.view(B, H, W, self.no)
+        dicts = [dict() for _ in range(self.n_heads)]
+        for (h, name, _, _, c2, col) in self.branches:
+            dicts[h][name] = o4[..., col:col + c2.out_channels].permute(0, 3, 1, 2)
+        dicts = [{n: d[n] for n in self.names} for d in dicts]       # the reference's key order
+        return o4, dicts
+
+
 class Radar_CenterHead(nn.Module):
     FEATURE_KEY = 'radar_spatial_features_2d'
     IS_TEACHER = False
@@ -256,7 +360,15 @@ class Radar_CenterHead(nn.Module):
         # ---- focal loss on all heat-map channels at once; per-head normalisation by that head's positives
         nc = [p['hm'].shape[1] for p in pred_dicts]
         head_of_ch = A.const_tensor(("head_of_ch", tuple(nc)), [h for h, c in enumerate(nc) for _ in range(c)], dev, torch.int64)
-        hm = self.sigmoid(torch.cat([p['hm'] for p in pred_dicts], dim=1))
+        # batched branches (head_forward): all maps live in ONE (B, H, W, NO) tensor, columns [hm | center | ... ], heads inner
+        stacked = self.forward_ret_dict.get('pred_stacked', None)
+        if stacked is not None and any(len(set(w)) != 1 for n, (_, w) in stacked[1].items() if n != 'hm'):
+            stacked = None
+        if stacked is not None:
+            o4, groups = stacked
+            hm = self.sigmoid(o4[..., groups['hm'][0]:groups['hm'][0] + sum(groups['hm'][1])].permute(0, 3, 1, 2))
+        else:
+            hm = self.sigmoid(torch.cat([p['hm'] for p in pred_dicts], dim=1))
         gt = st['heatmaps']
         pos_inds = gt.eq(1).float()
         neg_inds = gt.lt(1).float()
@@ -269,6 +381,11 @@ class Radar_CenterHead(nn.Module):
         B = pred_dicts[0]['center'].shape[0]
 
         def stk(name):
+            if stacked is not None:
+                c0, widths = groups[name]
+                c = widths[0]
+                Bq, Hq, Wq, _ = o4.shape
+                return o4[..., c0:c0 + nh * c].reshape(Bq, Hq, Wq, nh, c).permute(3, 0, 4, 1, 2).reshape(nh * Bq, c, Hq, Wq)
             return torch.cat([p[name] for p in pred_dicts], dim=0)
 
         center, center_z, dim_, rot, vel, iou = [stk(n) for n in ('center', 'center_z', 'dim', 'rot', 'vel', 'iou')]
@@ -362,6 +479,15 @@ class Radar_CenterHead(nn.Module):
     # ------------------------------------------------------------------ forward
     def head_forward(self, spatial_features_2d):
         x = D.conv_bn_act(spatial_features_2d, self.shared_conv[0], self.shared_conv[1], None, act=1, return_rows=True)
+        self.forward_ret_dict.pop('pred_stacked', None)
+        if x[0].is_cuda and self.model_cfg.get('BATCH_BRANCHES', True):
+            if getattr(self, '_branch_plan', None) is None:
+                self._branch_plan = (_BranchBatch.build(self),)          # (None,) = not batchable, decided once
+            plan = self._branch_plan[0]
+            res = plan.run(x) if plan is not None else None
+            if res is not None:
+                self.forward_ret_dict['pred_stacked'] = (res[0], plan.groups)
+                return res[1]
         return [head(x) for head in self.heads_list]
 
     def forward(self, data_dict):

@@ -99,7 +99,33 @@ def test_batched_head_loss_equals_per_head_loss_and_oracle(monkeypatch):
     for k in tb_p:
         assert abs(float(tb_b[k]) - float(tb_p[k])) <= 1e-4 * abs(float(tb_p[k])) + 1e-6, k
         assert abs(float(tb_b[k]) - float(otb[k])) <= 1e-4 * abs(float(otb[k])) + 1e-6, k
+    # the stacked-output form produced by the batched branch plan: one (B, H, W, NO) tensor, columns [hm | center | ...], heads inner
+    names = ["hm"] + list(ohead.HEAD_OUT.keys())
+    groups, cols, c0 = {}, [], 0
+    for n in names:
+        widths = [p[n].shape[1] for p in preds]
+        groups[n] = (c0, widths)
+        cols += [p[n].detach() for p in preds]
+        c0 += sum(widths)
+    o4 = torch.cat(cols, dim=1).permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+    col = 0
+    views = [dict() for _ in preds]
+    for n in names:
+        for h, p in enumerate(preds):
+            views[h][n] = o4[..., col:col + p[n].shape[1]].permute(0, 3, 1, 2)
+            col += p[n].shape[1]
+    m.forward_ret_dict = {"pred_dicts": views, "target_dicts": td, "pred_stacked": (o4, groups)}
+    loss_s, tb_s = m.get_loss()
+    assert abs(float(loss_s) - float(loss_p)) < 1e-4 * abs(float(loss_p))
+    for k in tb_p:
+        assert abs(float(tb_s[k]) - float(tb_p[k])) <= 1e-4 * abs(float(tb_p[k])) + 1e-6, k
+    (g_o4,) = torch.autograd.grad(loss_s.sum(), [o4])
+    m.forward_ret_dict = {"pred_dicts": preds, "target_dicts": td}
     gb = torch.autograd.grad(loss_b.sum(), [preds[1]["hm"], preds[4]["dim"], preds[0]["iou"]])
     gp = torch.autograd.grad(loss_p.sum(), [preds[1]["hm"], preds[4]["dim"], preds[0]["iou"]])
     for a, b in zip(gb, gp):
         assert float((a - b).abs().max()) <= 1e-5 * (float(b.abs().max()) + 1e-6)
+    c_hm1 = groups["hm"][0] + preds[0]["hm"].shape[1]
+    c_dim4 = groups["dim"][0] + 4 * 3
+    for a, b in ((g_o4[..., c_hm1:c_hm1 + preds[1]["hm"].shape[1]], gp[0]), (g_o4[..., c_dim4:c_dim4 + 3], gp[1])):
+        assert float((a.permute(0, 3, 1, 2) - b).abs().max()) <= 1e-5 * (float(b.abs().max()) + 1e-6)

@@ -254,7 +254,8 @@ def test_conv_epilogue_and_fused_stats():
     close(stats[:Cout], pre.sum(0), atol=2e-4); close(stats[Cout:], (pre * pre).sum(0), atol=2e-4)
 
 
-@pytest.mark.parametrize("C,rows,act,res", [(32, 5000, 1, True), (256, 777, 1, False), (256, 1000, 2, False), (64, 300, 0, False)])
+@pytest.mark.parametrize("C,rows,act,res", [(32, 5000, 1, True), (256, 777, 1, False), (256, 1000, 2, False), (64, 300, 0, False),
+                                            (2688, 600, 1, False), (1100, 90, 1, True)])   # > 512 columns: chunked column reduction
 def test_batchnorm_train_forward_backward(C, rows, act, res):
     A, K, SP = _mods()
     rng = np.random.default_rng(C + rows)
@@ -366,3 +367,45 @@ def test_depthwise_conv_forward_and_backward(C, H, W, K):
     close(xd.grad, xr.grad, what="dwconv dgrad")
     close(cd.weight.grad, conv.weight.grad, atol=2e-4, what="dwconv wgrad")
     close(cd.bias.grad, conv.bias.grad, atol=2e-4, what="dwconv bias grad")
+
+
+@pytest.mark.parametrize("B,H,W,n_list", [(2, 16, 16, (1, 2, 3, 2, 2, 1, 1)), (1, 13, 10, (3, 4, 1)), (3, 8, 24, (2,))])
+def test_narrow_branch_convs_forward_and_backward(B, H, W, n_list):
+    """rd_nconv_{fwd,dgrad,wgrad} (all head branches' final 64 -> n convs in one launch) vs torch conv2d per branch."""
+    A, K, SP = _mods()
+    rng = np.random.default_rng(B * 100 + H)
+    NB = len(n_list)
+    cols = np.concatenate([[0], np.cumsum(n_list)]).tolist()
+    NO = cols[-1]
+    y = torch.from_numpy(rng.normal(size=(B, H, W, NB * 64)).astype(np.float32))
+    w = torch.from_numpy((rng.normal(size=(NO, 64, 3, 3)) * 0.1).astype(np.float32))
+    b = torch.from_numpy(rng.normal(size=NO).astype(np.float32))
+    go = torch.from_numpy(rng.normal(size=(B, H, W, NO)).astype(np.float32))
+    yr, wr, br = y.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.cat([F.conv2d(yr[..., 64 * i:64 * i + 64].permute(0, 3, 1, 2), wr[cols[i]:cols[i + 1]], br[cols[i]:cols[i + 1]], padding=1)
+                     for i in range(NB)], dim=1).permute(0, 2, 3, 1)
+    (ref * go).sum().backward()
+    tab = K.BranchTable([64 * i for i in range(NB)], cols[:-1], list(n_list))
+    yd = y.reshape(-1, NB * 64).to(DEV).requires_grad_(True)
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    A.begin_step(torch.device(DEV))
+    out = A.nconv(yd, wd, bd, B, H, W, tab)
+    close(out, ref.reshape(-1, NO), what="nconv forward")
+    (out * go.reshape(-1, NO).to(DEV)).sum().backward()
+    close(yd.grad, yr.grad.reshape(-1, NB * 64), what="nconv dgrad")
+    close(wd.grad, wr.grad, what="nconv wgrad")
+    close(bd.grad, br.grad, what="nconv bias grad")
+    with torch.no_grad():
+        close(A.nconv(yd.detach(), wd.detach(), None, B, H, W, tab), (ref - br.detach()).reshape(-1, NO), what="nconv forward, no bias")
+
+
+def test_narrow_branch_convs_reject_bad_tables():
+    A, K, SP = _mods()
+    y = torch.zeros((64, 128), device=DEV)
+    w = torch.zeros((3, 64, 3, 3), device=DEV)
+    tab = K.BranchTable([0, 64], [0, 1], [1, 2])
+    with pytest.raises(RuntimeError):
+        K.nconv_fwd(y[:, :64].contiguous(), w, None, 1, 8, 8, tab)          # second branch's channels are outside the row
+    tab5 = K.BranchTable([0], [0], [5])
+    with pytest.raises(RuntimeError):
+        K.nconv_fwd(y, torch.zeros((5, 64, 3, 3), device=DEV), None, 1, 8, 8, tab5)   # 5 outputs per branch: not supported

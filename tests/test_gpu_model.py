@@ -228,6 +228,53 @@ def test_center_head_golden(golden_dir):
         close(v, g["tb_" + k], rtol=1e-3, atol=1e-5, what=k)
 
 
+@pytest.mark.parametrize("training", [True, False])
+def test_center_head_batched_branches_equal_per_branch_path(training):
+    """The MI355X execution plan (all 42 branches: one conv + one BatchNorm + one narrow-conv launch) against the reference-shaped
+    per-branch loop of the same module: predictions, loss, running statistics and parameter gradients."""
+    import copy
+    g = np.random.default_rng(31)
+    feat = torch.from_numpy(g.normal(0, 1, size=(2, 256, 16, 16)).astype(np.float32))
+    batch = make_batch(batch_size=2, n_lidar=16, n_radar=16, n_boxes=12, grid=128, seed=3)
+    gt = torch.from_numpy(batch["gt_boxes"]).to(DEV)
+    results = []
+    base = _head(seed=15)
+    for batched in (True, False):
+        m = copy.deepcopy(base)
+        m.model_cfg = copy.deepcopy(m.model_cfg); m.model_cfg["BATCH_BRANCHES"] = batched
+        if training:
+            m.train()
+            d = m({"radar_spatial_features_2d": _cl(feat), "gt_boxes": gt, "gt_boxes_host": batch["gt_boxes"], "batch_size": 2})
+            assert ("pred_stacked" in m.forward_ret_dict) == batched
+            loss, tb = m.get_loss()
+            loss.sum().backward()
+            from radardistill_amd import autograd as A
+            A.end_forward()
+            results.append((d["radar_pred_dicts"], loss.detach(), {k: p.grad.detach().clone() for k, p in m.named_parameters()},
+                            {k: v.detach().clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}))
+        else:
+            m.eval()
+            for p in m.parameters():
+                p.requires_grad_(False)
+            with torch.no_grad():
+                x = _cl(feat)
+                preds = m.head_forward(x)
+            assert ("pred_stacked" in m.forward_ret_dict) == batched
+            results.append((preds, None, {}, {}))
+    (pa, la, ga, sa), (pb, lb, gb, sb) = results
+    for da, db in zip(pa, pb):
+        assert list(da.keys()) == list(db.keys())
+        for k in da:
+            assert da[k].shape == db[k].shape
+            close(da[k], db[k], what=f"pred {k}")
+    if training:
+        close(la, lb, rtol=1e-4)
+        for k in gb:
+            close(ga[k], gb[k], rtol=2e-3, atol=2e-4, what=f"grad {k}")
+        for k in sb:
+            close(sa[k], sb[k], what=k)
+
+
 def test_conv5_golden(golden_dir):
     from functools import partial
     from radardistill_amd.pcdet.models.backbones_3d.spconv_backbone_2d import BasicBlock, post_act_block_dense
