@@ -148,6 +148,7 @@ def main():
         torch.cuda.synchronize()
 
     K.CONV_PROFILE = []
+    K.WGRAD_PROFILE = [] if os.environ.get("RD_BENCH_SHAPES") else None
     barrier()
     t0 = time.perf_counter()
     for it in range(args.warmup, args.warmup + args.steps):
@@ -155,6 +156,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof, K.CONV_PROFILE = K.CONV_PROFILE, None
+    wprof, K.WGRAD_PROFILE = K.WGRAD_PROFILE, None
     last_loss = float(loss)
     roofline_note = "HIP events around every launch of the kernel inside the timed region"
     prof_steps = args.steps
@@ -175,8 +177,14 @@ def main():
             for shape, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 print(f"[shape in_rows,Cin,Cout,taps,mode,tile={shape}] launches/step {n / prof_steps:.1f} ms/step {ms / prof_steps:.3f} "
                       f"TF/s {fl / (ms * 1e-3) / 1e12:.1f}", file=sys.stderr)
+            wagg = {}
+            for e0, e1, pairs, f, shape in (wprof or []):
+                a = wagg.setdefault(shape, [0, 0.0, 0.0]); a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += (f if pairs is None else float(pairs.item()) * f)
+            for shape, (n, ms, fl) in sorted(wagg.items(), key=lambda kv: -kv[1][1]):
+                print(f"[wgrad in_rows,Cin,Cout,taps,mode={shape}] launches/step {n / prof_steps:.1f} ms/step {ms / prof_steps:.3f} "
+                      f"TF/s {fl / (ms * 1e-3) / 1e12:.1f}", file=sys.stderr)
         # roofline of the dominant kernel: the 128x128-tile instantiation k_conv_igemm<128,128,2,2,false>
-        sel = [i for i, p in enumerate(prof) if p[4][5] == 128]
+        sel = [i for i, p in enumerate(prof) if p[4][5] == 128 and p[4][4] < 10]     # mode >= 10: data-gradient (BT) instantiation
         kernel_ms = [all_ms[i] for i in sel]
         flops = [all_flops[i] for i in sel]
         n_launch = len(sel)

@@ -129,8 +129,18 @@ int rd_conv_fwd(const float *in, int in_rows, int Cin, const float *weight_k, in
 int rd_set_conv_math(int mode);
 int rd_get_conv_math(void);
 
-/* Weight gradient: grad_wk[Cout][taps][Cin] += sum_j grad_out[j][:]^T (x) in[src(j,t)][:]  (atomic accumulation,
- * caller zeroes).  Cout % 32 == 0 or Cout < 32 handled by masking; Cin % 32 == 0. */
+/* Data gradient on the forward weights: grad_in[i][c] = sum_t sum_n grad_out[src_bwd(i,t)][n] * weight_k[n][t][c], with weight_k the
+ * FORWARD kernel layout [Cout][taps][Cin] (the kernel reads it transposed; no re-laid-out copy) and idx the backward index
+ * (transposed neighbour table / flip = 1 for sub-manifold, the transposed geometry for dense convolutions).  Cout % 32 == 0
+ * (zero-pad narrower outputs and use rd_conv_fwd), Cin % 4 == 0; exact-fp32 mode only.
+ * Replaces spconv's backward-data implicit GEMM and cuDNN's conv backward-data (autograd of spconv_backbone_2d.py / Conv2d). */
+int rd_conv_dgrad(const float *grad_out, int out_rows, int Cout, const float *weight_k, int taps, float *grad_in, int in_rows, int Cin,
+                  const rd_conv_index *idx, void *stream);
+
+/* Weight gradient: grad_wk[Cout][taps][Cin] += sum_j grad_out[j][:]^T (x) in[src(j,t)][:]  (atomic accumulation, caller zeroes).
+ * Kernel layout only: each atomic wave-instruction then adds two contiguous 128-byte row segments, the shape global float atomics
+ * run at full rate in (a tap-strided parameter layout would be ~17x slower; rd_weight_layout kinds 4/5 convert afterwards).
+ * Cout % 32 == 0 or Cout < 32 handled by masking; Cin % 32 == 0. */
 int rd_conv_wgrad(const float *in, int in_rows, int Cin, const float *grad_out, int out_rows, int Cout, int taps,
                   const rd_conv_index *idx, float *grad_wk, void *stream);
 

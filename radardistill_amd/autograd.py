@@ -175,15 +175,18 @@ class _ConvFn(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             wk = ctx.wk
-            go, Cp = grad_out, Cout
-            if Cout % 32 != 0:      # narrow heads (1..3, 27 channels): zero-pad the contraction dim to the kernel's K step
-                Cp = (Cout + 31) // 32 * 32
-                go = torch.nn.functional.pad(grad_out, (0, Cp - Cout))
-                wk = torch.nn.functional.pad(wk.reshape(Cout, -1), (0, 0, 0, Cp - Cout))
-            wd = K.weight_layout(wk.contiguous(), Cp, Cin, spec.taps, 2, False)          # [Cin][taps][Cout]
-            gx = K.conv_fwd(go, wd, spec.taps, None, spec.in_rows, Cin, spec.bwd_ix, nbr_keepalive=spec.bwd_nbr)
+            if Cout % 32 == 0 and K.get_conv_math() == "f32":
+                gx = K.conv_dgrad(grad_out, wk, spec.taps, spec.in_rows, Cin, spec.bwd_ix, nbr_keepalive=spec.bwd_nbr)   # forward weights, read transposed
+            else:
+                go, Cp = grad_out, Cout
+                if Cout % 32 != 0:      # narrow outputs (27-channel DCN offsets): zero-pad the contraction dim to the kernel's K step
+                    Cp = (Cout + 31) // 32 * 32
+                    go = torch.nn.functional.pad(grad_out, (0, Cp - Cout))
+                    wk = torch.nn.functional.pad(wk.reshape(Cout, -1), (0, 0, 0, Cp - Cout))
+                wd = K.weight_layout(wk.contiguous(), Cp, Cin, spec.taps, 2, False)          # [Cin][taps][Cout]
+                gx = K.conv_fwd(go, wd, spec.taps, None, spec.in_rows, Cin, spec.bwd_ix, nbr_keepalive=spec.bwd_nbr)
             if _DEBUG and spec.fwd_nbr is not None:
-                w3 = wk.reshape(-1, spec.taps, Cin)[:Cout].double()
+                w3 = ctx.wk.reshape(-1, spec.taps, Cin)[:Cout].double()
                 ref = torch.zeros((spec.in_rows, Cin), dtype=torch.float64, device=x.device)
                 nb = spec.fwd_nbr.long()
                 for t in range(spec.taps):
@@ -191,7 +194,7 @@ class _ConvFn(torch.autograd.Function):
                     ref.index_add_(0, nb[o, t], grad_out[o].double() @ w3[:, t, :])
                 _dbg_report(f"conv dgrad Cin={Cin} Cout={Cout} rows {spec.out_rows}->{spec.in_rows} flip={spec.bwd_ix.flip}", gx.double(), ref)
         if ctx.needs_input_grad[1]:
-            gwk = K.conv_wgrad(x, grad_out, spec.taps, spec.fwd_ix)             # kernel layout
+            gwk = K.conv_wgrad(x, grad_out, spec.taps, spec.fwd_ix, nbr_keepalive=spec.fwd_nbr)             # kernel layout
             if spec.param_kind == 0:
                 gw = gwk.reshape(weight.shape)
             elif spec.param_kind == 1:

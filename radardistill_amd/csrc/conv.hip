@@ -16,16 +16,20 @@
 
 using namespace rd;
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool DEFORM>
+// BT = true: the weight operand is read TRANSPOSED, B[k][n] = w[k][tap][n] with w in the forward kernel layout [K][taps][N].
+// That is the data-gradient GEMM (K = forward Cout, N = forward Cin) on the forward weights as they are: no re-layout launch.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool DEFORM, bool BT = false>
 __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int MI = WM / 32, NI = WN / 32;
     constexpr int BP = BN / 32;  // B float4 loads per thread
     constexpr int AP = BM / 32;  // A float4 loads per thread
     static_assert(WAVES_M * WAVES_N == 4 && MI >= 1 && NI >= 1, "4 waves, each at least one 32x32 MFMA tile");
-    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDK];
+    constexpr int LDBT = BN + 4;                                     // BT: B tile stored [k][n], row stride BN + 4 floats
+    constexpr int BSZ = BT ? KB * LDBT : BN * LDK;                   // floats of one B tile
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM * LDK + BSZ)];
     __shared__ int s_tapmask;
-    constexpr int BUF = (BM + BN) * LDK;  // floats per buffer: [A tile 128 x 36][B tile BN x 36]
+    constexpr int BUF = BM * LDK + BSZ;  // floats per buffer: [A tile BM x 36][B tile]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WAVES_N, wn = wid % WAVES_N;
@@ -106,9 +110,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
         }
 #pragma unroll
         for (int p = 0; p < BP; ++p) {
-            int n = n0 + ld_r + 32 * p;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n < a.Cout) v = *reinterpret_cast<const f32x4 *>(a.w + ((int64_t)n * a.taps + cur_tap) * a.Cin + kc + ld_c);
+            if constexpr (BT) {
+                const int idx = tid + 256 * p, kr = idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
+                if (n < a.Cout) v = *reinterpret_cast<const f32x4 *>(a.w + ((int64_t)(kc + kr) * a.taps + cur_tap) * a.Cout + n);
+            } else {
+                const int n = n0 + ld_r + 32 * p;
+                if (n < a.Cout) v = *reinterpret_cast<const f32x4 *>(a.w + ((int64_t)n * a.taps + cur_tap) * a.Cin + kc + ld_c);
+            }
             rb[p] = v;
         }
     };
@@ -116,7 +125,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
 #pragma unroll
         for (int p = 0; p < AP; ++p) *reinterpret_cast<f32x4 *>(lds + buf * BUF + (ld_r + 32 * p) * LDK + ld_c) = ra[p];
 #pragma unroll
-        for (int p = 0; p < BP; ++p) *reinterpret_cast<f32x4 *>(lds + buf * BUF + BM * LDK + (ld_r + 32 * p) * LDK + ld_c) = rb[p];
+        for (int p = 0; p < BP; ++p) {
+            if constexpr (BT) {
+                const int idx = tid + 256 * p;
+                *reinterpret_cast<f32x4 *>(lds + buf * BUF + BM * LDK + (idx / (BN / 4)) * LDBT + (idx % (BN / 4)) * 4) = rb[p];
+            } else {
+                *reinterpret_cast<f32x4 *>(lds + buf * BUF + BM * LDK + (ld_r + 32 * p) * LDK + ld_c) = rb[p];
+            }
+        }
     };
 
     if (steps > 0) {
@@ -129,14 +145,22 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
         const int buf = s & 1;
         if (s + 1 < steps) load_tile(s + 1);
         const float *Ab = lds + buf * BUF + (wm * WM + fr) * LDK + 4 * fh;
-        const float *Bb = lds + buf * BUF + BM * LDK + (wn * WN + fr) * LDK + 4 * fh;
+        const float *Bb = BT ? lds + buf * BUF + BM * LDK + (4 * fh) * LDBT + wn * WN + fr
+                             : lds + buf * BUF + BM * LDK + (wn * WN + fr) * LDK + 4 * fh;
 #pragma unroll
         for (int kk = 0; kk < KB / 8; ++kk) {
             f32x4 af[MI], bf[NI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const f32x4 *>(Ab + i * 32 * LDK + kk * 8);
 #pragma unroll
-            for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const f32x4 *>(Bb + j * 32 * LDK + kk * 8);
+            for (int j = 0; j < NI; ++j) {
+                if constexpr (BT) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bf[j][q] = Bb[(kk * 8 + q) * LDBT + j * 32];
+                } else {
+                    bf[j] = *reinterpret_cast<const f32x4 *>(Bb + j * 32 * LDK + kk * 8);
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -272,6 +296,34 @@ extern "C" int rd_conv_fwd(const float *in, int in_rows, int Cin, const float *w
         k_conv_igemm<128, 32, 4, 1, false><<<grid, block, 0, st>>>(a);
     }
     return check_launch("rd_conv_fwd");
+}
+
+// Data gradient on the FORWARD weights (no transposed copy): grad_in[i][c] = sum_t sum_n grad_out[src_bwd(i,t)][n] * w[n][t][c].
+// idx is the backward index (transposed table / flip for sub-manifold, transposed geometry for dense convolutions).
+extern "C" int rd_conv_dgrad(const float *grad_out, int out_rows, int Cout, const float *weight_k, int taps, float *grad_in, int in_rows,
+                             int Cin, const rd_conv_index *idx, void *stream) {
+    RD_REQUIRE(Cout > 0 && Cout % KB == 0, "rd_conv_dgrad: Cout=%d must be a multiple of %d (zero-pad narrow outputs)", Cout, KB);
+    RD_REQUIRE(Cin > 0 && Cin % 4 == 0 && in_rows >= 0 && out_rows >= 0, "rd_conv_dgrad: bad sizes");
+    RD_REQUIRE(g_conv_math == 0, "rd_conv_dgrad: exact-fp32 mode only (bf16x3 uses rd_weight_layout(kind 2) + rd_conv_fwd)");
+    RD_REQUIRE(idx && idx->mode != 3, "rd_conv_dgrad: deformable sampling has its own data gradient (rd_dcn_bwd_data)");
+    int rc = validate_index(idx, taps, out_rows, in_rows, "rd_conv_dgrad");
+    if (rc) return rc;
+    if (in_rows == 0) return RD_OK;
+    // GEMM view: rows = in_rows, K = Cout (forward), N = Cin (forward)
+    ConvArgs a{grad_out, out_rows, Cout, weight_k, taps, nullptr, grad_in, in_rows, Cin, *idx, nullptr, nullptr, nullptr, 0, nullptr};
+    hipStream_t st = S(stream);
+    dim3 block(256);
+    const int64_t big_blocks = cdiv(in_rows, 128) * cdiv(Cin, 128);
+    if (Cin > 64) {
+        if (big_blocks >= 384) k_conv_igemm<128, 128, 2, 2, false, true><<<dim3(xcd_grid(cdiv(in_rows, 128), cdiv(Cin, 128))), block, 0, st>>>(a);
+        else k_conv_igemm<64, 64, 2, 2, false, true><<<dim3(xcd_grid(cdiv(in_rows, 64), cdiv(Cin, 64))), block, 0, st>>>(a);
+    } else if (Cin > 32) {
+        if (cdiv(in_rows, 128) >= 384) k_conv_igemm<128, 64, 2, 2, false, true><<<dim3(xcd_grid(cdiv(in_rows, 128), 1)), block, 0, st>>>(a);
+        else k_conv_igemm<64, 64, 2, 2, false, true><<<dim3(xcd_grid(cdiv(in_rows, 64), 1)), block, 0, st>>>(a);
+    } else {
+        k_conv_igemm<128, 32, 4, 1, false, true><<<dim3(xcd_grid(cdiv(in_rows, 128), 1)), block, 0, st>>>(a);
+    }
+    return check_launch("rd_conv_dgrad");
 }
 
 // ---------------------------------------------------------------------------------------------- weight gradient

@@ -198,7 +198,42 @@ def conv_fwd(x, weight_k, taps, bias, out_rows, Cout, ix, scale=None, shift=None
     return out
 
 
-def conv_wgrad(x, grad_out, taps, ix):
+def conv_dgrad(grad_out, weight_k, taps, in_rows, Cin, ix_bwd, nbr_keepalive=None):
+    """grad_out (out_rows, Cout), weight_k the FORWARD kernel layout (Cout, taps, Cin) -> grad_in (in_rows, Cin).  fp32 mode only."""
+    _chk(grad_out, f32, "dgrad grad_out", 2)
+    _chk(weight_k, f32, "dgrad weight")
+    out_rows, Cout = grad_out.shape
+    if weight_k.numel() != Cout * taps * Cin:
+        raise RuntimeError(f"conv_dgrad: weight has {weight_k.numel()} elements, expected {Cout}*{taps}*{Cin}")
+    if ix_bwd.mode == 0 and nbr_keepalive is not None:
+        if nbr_keepalive.shape != (in_rows, taps) or nbr_keepalive.dtype != i32 or not nbr_keepalive.is_contiguous():
+            raise RuntimeError(f"backward neighbour table shape {tuple(nbr_keepalive.shape)} != ({in_rows}, {taps})")
+    gx = torch.empty((in_rows, Cin), dtype=f32, device=grad_out.device)
+    prof = CONV_PROFILE is not None and Cin > 64
+    tile = 128 if ((in_rows + 127) // 128) * ((Cin + 127) // 128) >= 384 else 64
+    if prof:
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(native.lib().rd_conv_dgrad(_p(grad_out), out_rows, Cout, _p(weight_k), taps, _p(gx), in_rows, Cin, ctypes.byref(ix_bwd), _stream()),
+          "rd_conv_dgrad")
+    if prof:
+        e1.record()
+        if ix_bwd.mode == 0:
+            pairs = getattr(nbr_keepalive, "_rd_pairs", None) if nbr_keepalive is not None else None
+            if pairs is None and nbr_keepalive is not None:
+                pairs = (nbr_keepalive >= 0).sum()
+                nbr_keepalive._rd_pairs = pairs
+            CONV_PROFILE.append((e0, e1, pairs, 2.0 * Cin * Cout, (out_rows, Cout, Cin, taps, 10 + ix_bwd.mode, tile)))
+        else:
+            CONV_PROFILE.append((e0, e1, None, 2.0 * in_rows * taps * Cin * Cout, (out_rows, Cout, Cin, taps, 10 + ix_bwd.mode, tile)))
+    return gx
+
+
+# Optional timing hook for the weight-gradient kernel (bench.py RD_BENCH_SHAPES=1): (start, end, pairs, flops factor, shape)
+WGRAD_PROFILE = None
+
+
+def conv_wgrad(x, grad_out, taps, ix, nbr_keepalive=None):
     """-> grad weight in kernel layout (Cout, taps, Cin)."""
     _chk(x, f32, "wgrad input", 2)
     _chk(grad_out, f32, "wgrad grad_out", 2)
@@ -206,7 +241,22 @@ def conv_wgrad(x, grad_out, taps, ix):
     out_rows, Cout = grad_out.shape
     from . import autograd as _A
     gw = _A.zeros_accum(Cout * taps * Cin, x.device).view(Cout, taps, Cin)          # zero-initialised accumulator (atomics)
-    check(native.lib().rd_conv_wgrad(_p(x), in_rows, Cin, _p(grad_out), out_rows, Cout, taps, ctypes.byref(ix), _p(gw), _stream()), "rd_conv_wgrad")
+    prof = WGRAD_PROFILE is not None
+    if prof:
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(native.lib().rd_conv_wgrad(_p(x), in_rows, Cin, _p(grad_out), out_rows, Cout, taps, ctypes.byref(ix), _p(gw), _stream()),
+          "rd_conv_wgrad")
+    if prof:
+        e1.record()
+        pairs = None
+        if ix.mode == 0 and nbr_keepalive is not None:
+            pairs = getattr(nbr_keepalive, "_rd_pairs", None)
+            if pairs is None:
+                pairs = (nbr_keepalive >= 0).sum()
+                nbr_keepalive._rd_pairs = pairs
+        WGRAD_PROFILE.append((e0, e1, pairs, 2.0 * Cin * Cout if pairs is not None else 2.0 * out_rows * taps * Cin * Cout,
+                              (in_rows, Cin, Cout, taps, ix.mode)))
     return gw
 
 
@@ -501,11 +551,15 @@ def nconv_wgrad(y, grad_out, B, H, W, tab):
 
 
 # ------------------------------------------------------------------------------------------ arithmetic mode of the conv kernels
+_CONV_MATH = ["f32"]
+
+
 def set_conv_math(mode):
     """'f32': exact fp32 MFMA (default).  'bf16x3': split-bf16 MFMA, ~4e-6 relative error (conv_b3.hip)."""
     code = {"f32": 0, "bf16x3": 1}[mode]
     check(native.lib().rd_set_conv_math(code), "rd_set_conv_math")
+    _CONV_MATH[0] = mode
 
 
 def get_conv_math():
-    return {0: "f32", 1: "bf16x3"}[native.lib().rd_get_conv_math()]
+    return _CONV_MATH[0]
