@@ -327,12 +327,13 @@ extern "C" int rd_conv_dgrad(const float *grad_out, int out_rows, int Cout, cons
 }
 
 // ---------------------------------------------------------------------------------------------- weight gradient
-// grad_w[n][t][c] += sum_j grad_out[j][n] * in[src(j,t)][c].  GEMM with M = Cout tile (128), N = Cin tile (BNW), K = rows.
+// grad_w[n][t][c] += sum_j grad_out[j][n] * in[src(j,t)][c].  GEMM with M = Cout tile (128), N = Cin tile (BNW = 64 or 128), K = rows.
 // Both operands are k-major in memory (rows x channels), so LDS tiles are stored [k][m] and read with ds_read_b32
-// (consecutive lanes -> consecutive channels: conflict free).  Split over row chunks; fp32 atomics combine the chunks.
+// (consecutive lanes -> consecutive channels: conflict free).  Split over row chunks; fp32 atomics combine the chunks: every
+// atomic wave-instruction adds two contiguous 128-byte row segments of the kernel-layout gradient (the full-rate shape).
+// BNW = 128 halves the operand bytes staged per flop (the 64-wide tile is operand-delivery bound) and is used when Cin >= 128.
 constexpr int WG_KB = 32;   // rows per K step
 constexpr int WG_BM = 128;  // Cout tile
-constexpr int WG_BN = 64;   // Cin tile
 
 struct WgradArgs {
     const float *in;
@@ -352,41 +353,60 @@ __device__ __forceinline__ int src_row_w(const WgradArgs &a, int j, int t) {
     return src_row(c, j, t);
 }
 
-template <bool DEFORM>
+template <bool DEFORM, int BNW>
 __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const WgradArgs a) {
+    constexpr int NJ = BNW / 64;   // 32-wide MFMA column tiles per wave (wave tile 64 couts x BNW/2 cins)
+    constexpr int XP = BNW / 32;   // float4 loads of the input tile per thread
     __shared__ __attribute__((aligned(16))) float G_l[2][WG_KB][WG_BM + 4];  // grad_out tile [k][cout]
-    __shared__ __attribute__((aligned(16))) float X_l[2][WG_KB][WG_BN + 4];  // gathered input tile [k][cin]
+    __shared__ __attribute__((aligned(16))) float X_l[2][WG_KB][BNW + 4];    // gathered input tile [k][cin]
     __shared__ int s_any[2];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;  // 2x2 waves: wave tile 64 (cout) x 32 (cin)
+    const int wm = wid >> 1, wn = wid & 1;  // 2x2 waves
     const int tile = blockIdx.y;            // (tap, mt, nt)
-    const int n_nt = (a.Cin + WG_BN - 1) / WG_BN;
+    const int n_nt = (a.Cin + BNW - 1) / BNW;
     const int n_mt = (a.Cout + WG_BM - 1) / WG_BM;
     const int t = tile / (n_mt * n_nt);
     const int mt = (tile / n_nt) % n_mt, nt = tile % n_nt;
-    const int co0 = mt * WG_BM, ci0 = nt * WG_BN;
+    const int co0 = mt * WG_BM, ci0 = nt * BNW;
     const int r_begin = blockIdx.x * a.rows_per_block;
     const int r_end = min(a.out_rows, r_begin + a.rows_per_block);
 
-    f32x16 acc[2];
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // loaders: G tile 32 rows x 128 couts = 1024 float4 -> 4 / thread; X tile 32 rows x 64 cins = 512 float4 -> 2 / thread
-    const int g_r = tid >> 5, g_c = (tid & 31) * 4;  // rows g_r + 8*p, p<4
-    const int x_r = tid >> 4, x_c = (tid & 15) * 4;  // rows x_r + 16*p, p<2
-    f32x4 rg[4], rx[2];
+    // loaders: G tile 32 rows x 128 couts = 1024 float4 -> 4 / thread; X tile 32 rows x BNW cins -> XP / thread
+    const int g_r = tid >> 5, g_c = (tid & 31) * 4;                              // rows g_r + 8*p, p<4
+    constexpr int X_TPR = BNW / 4;                                               // threads per X row
+    const int x_r = tid / X_TPR, x_c = (tid % X_TPR) * 4;                        // rows x_r + (256/X_TPR)*p, p<XP
+    constexpr int X_RSTEP = 256 / X_TPR;
+    f32x4 rg[4], rx[XP];
     const int n_steps = (r_end - r_begin + WG_KB - 1) / WG_KB;
-    int any_next = 0;
+    int any_next = 0, cur_store_step = 0;
+    // dense geometry: every thread walks its XP rows with (b, oy, ox) cursors advanced by WG_KB rows per step -- the per-row
+    // divisions by the map size would otherwise sit in front of every gather of every K step
+    const bool dense = a.ix.mode == 1 || a.ix.mode == 2;
+    int cb[XP], cy[XP], cx[XP];
+    if (dense) {
+#pragma unroll
+        for (int p = 0; p < XP; ++p) {
+            const int j = r_begin + x_r + X_RSTEP * p;
+            cx[p] = j % a.ix.Wout;
+            cy[p] = (j / a.ix.Wout) % a.ix.Hout;
+            cb[p] = j / (a.ix.Wout * a.ix.Hout);
+        }
+    }
 
     auto load_tile = [&](int s) {
         const int r0 = r_begin + s * WG_KB;
         any_next = 0;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            int j = r0 + x_r + 16 * p;
+        for (int p = 0; p < XP; ++p) {
+            int j = r0 + x_r + X_RSTEP * p;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if constexpr (DEFORM) {
                 if (j < r_end) {
@@ -405,7 +425,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const WgradArgs a) {
                     }
                 }
             } else {
-                int src = (j < r_end) ? src_row_w(a, j, t) : -1;
+                int src = -1;
+                if (j < r_end) src = dense ? src_row_dense(a.ix, cb[p], cy[p], cx[p], t) : src_row_w(a, j, t);
+                if (dense) {  // advance the cursor to this thread's row of the next K step
+                    cx[p] += WG_KB;
+                    while (cx[p] >= a.ix.Wout) {
+                        cx[p] -= a.ix.Wout;
+                        if (++cy[p] == a.ix.Hout) {
+                            cy[p] = 0;
+                            ++cb[p];
+                        }
+                    }
+                }
                 if (src >= 0) {
                     any_next = 1;
                     if (ci0 + x_c < a.Cin) v = *reinterpret_cast<const f32x4 *>(a.in + (int64_t)src * a.Cin + ci0 + x_c);
@@ -433,16 +464,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const WgradArgs a) {
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) *reinterpret_cast<f32x4 *>(&X_l[buf][x_r + 16 * p][x_c]) = rx[p];
+        for (int p = 0; p < XP; ++p) *reinterpret_cast<f32x4 *>(&X_l[buf][x_r + X_RSTEP * p][x_c]) = rx[p];
 #pragma unroll
         for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(&G_l[buf][g_r + 8 * p][g_c]) = rg[p];
-        if (any_next) s_any[buf] = 1;
+        if (any_next) s_any[buf] = cur_store_step;   // tag = 1 + index of the K step this tile belongs to (no reset pass needed)
     };
 
     if (tid < 2) s_any[tid] = 0;
     __syncthreads();
     if (n_steps > 0) {
         load_tile(0);
+        cur_store_step = 1;
         store_tile(0);
     }
     __syncthreads();
@@ -450,33 +482,52 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const WgradArgs a) {
     for (int s = 0; s < n_steps; ++s) {
         const int buf = s & 1;
         if (s + 1 < n_steps) load_tile(s + 1);
-        if (s_any[buf]) {  // block-uniform: skip K steps whose 32 rows have no source for this tap
+        if (s_any[buf] == s + 1) {  // block-uniform: skip K steps whose 32 rows have no source for this tap
+            // operands of k-pair kk+1 are fetched from LDS while the MFMAs of k-pair kk run (explicit register double buffer:
+            // the compiler otherwise re-uses one register set and waits for LDS in front of every group of MFMAs)
+            float av[2][2], bv[2][NJ];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[0][i] = G_l[buf][fh][wm * 64 + i * 32 + fr];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bv[0][j] = X_l[buf][fh][wn * (BNW / 2) + j * 32 + fr];
 #pragma unroll
             for (int kk = 0; kk < WG_KB / 2; ++kk) {
-                const int k = kk * 2 + fh;
-                float b = X_l[buf][k][wn * 32 + fr];
-                float a0 = G_l[buf][k][wm * 64 + fr];
-                float a1 = G_l[buf][k][wm * 64 + 32 + fr];
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
+                const int cur = kk & 1, nxt = cur ^ 1;
+                if (kk + 1 < WG_KB / 2) {
+                    const int k = (kk + 1) * 2 + fh;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) av[nxt][i] = G_l[buf][k][wm * 64 + i * 32 + fr];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) bv[nxt][j] = X_l[buf][k][wn * (BNW / 2) + j * 32 + fr];
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep the LDS reads above in front of this group of MFMAs
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
             }
         }
-        __syncthreads();            // everyone done reading buf (and s_any[buf])
-        if (tid == 0) s_any[buf] = 0;
-        if (s + 1 < n_steps) store_tile(buf ^ 1);
+        if (s + 1 < n_steps) {      // the other buffer was last read in step s-1, which ended with the barrier below
+            cur_store_step = s + 2;
+            store_tile(buf ^ 1);
+        }
         __syncthreads();
     }
     // accumulate into grad_w[co][t][ci]
-    const int ci = ci0 + wn * 32 + fr;
-    if (ci < a.Cin) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < NJ; ++j) {
+        const int ci = ci0 + wn * (BNW / 2) + j * 32 + fr;
+        if (ci < a.Cin) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                float v = acc[i][r];
-                if (co < a.Cout && v != 0.f) atomicAdd(&a.gw[((int64_t)co * a.taps + t) * a.Cin + ci], v);
-            }
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    float v = acc[i][j][r];
+                    if (co < a.Cout && v != 0.f) atomicAdd(&a.gw[((int64_t)co * a.taps + t) * a.Cin + ci], v);
+                }
+        }
     }
 }
 
@@ -487,20 +538,41 @@ extern "C" int rd_conv_wgrad(const float *in, int in_rows, int Cin, const float 
     int rc = validate_index(idx, taps, in_rows, out_rows, "rd_conv_wgrad");
     if (rc) return rc;
     if (out_rows == 0) return RD_OK;
-    const int n_mt = (int)cdiv(Cout, WG_BM), n_nt = (int)cdiv(Cin, WG_BN);
+    // 128-wide Cin tiles when that still leaves >= 32 (tap, tile) pairs to spread over the chip (3x3 convs); 1x1 convs keep 64
+    const bool wide = Cin >= 128 && Cout >= 64 && (int64_t)taps * cdiv(Cout, WG_BM) * cdiv(Cin, 128) >= 32;
+    const int bn = wide ? 128 : 64;
+    const int n_mt = (int)cdiv(Cout, WG_BM), n_nt = (int)cdiv(Cin, bn);
     const int tiles = taps * n_mt * n_nt;
-    // aim for ~2048 blocks, at least 256 rows per block
-    int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(cdiv(out_rows, 256), cdiv(2048, tiles)));
+    // Row chunks.  512 workgroups are resident at once (two per CU); a launch runs in ceil(chunks*tiles/512) rounds of
+    // rows/chunks rows each, and every block ends with an atomic pass over its tile (memory-side atomics, ~1.3 TB/s chip-wide:
+    // ~50k cycles per round for 128x128 tiles).  Pick the chunk count with the smallest modelled time; >= 256 rows per block.
+    int64_t chunks = 1;
+    if (taps == 1) {  // 1x1 convs: little work per (tile, chunk), latency bound -> more, smaller blocks (measured 75 us vs 102 us)
+        chunks = std::max<int64_t>(1, std::min<int64_t>(cdiv(out_rows, 256), cdiv(2048, tiles)));
+    } else {
+        const int64_t max_chunks = std::max<int64_t>(1, std::min<int64_t>(cdiv(out_rows, 256), 128));
+        double best = 1e30;
+        for (int64_t c = 1; c <= max_chunks; ++c) {
+            const double rounds = (double)cdiv(c * tiles, 512);
+            const double cost = rounds * ((double)cdiv(out_rows, c) * 2.0 * bn + 50000.0 * bn / 128.0);
+            if (cost < best) { best = cost; chunks = c; }
+        }
+    }
     int rows_per_block = (int)(cdiv(cdiv(out_rows, chunks), WG_KB) * WG_KB);
     chunks = cdiv(out_rows, rows_per_block);
     WgradArgs a{in, in_rows, Cin, grad_out, out_rows, Cout, taps, *idx, grad_wk, rows_per_block};
     dim3 grid((unsigned)chunks, (unsigned)tiles);
-    if (idx->mode == 3) k_conv_wgrad<true><<<grid, 256, 0, S(stream)>>>(a);
-    else k_conv_wgrad<false><<<grid, 256, 0, S(stream)>>>(a);
+    hipStream_t st = S(stream);
+    if (idx->mode == 3) {
+        if (wide) k_conv_wgrad<true, 128><<<grid, 256, 0, st>>>(a);
+        else k_conv_wgrad<true, 64><<<grid, 256, 0, st>>>(a);
+    } else {
+        if (wide) k_conv_wgrad<false, 128><<<grid, 256, 0, st>>>(a);
+        else k_conv_wgrad<false, 64><<<grid, 256, 0, st>>>(a);
+    }
     return check_launch("rd_conv_wgrad");
 }
 
-// ---------------------------------------------------------------------------------------------- weight layouts
 __global__ void k_weight_layout(const float *src, float *dst, int Cout, int Cin, int taps, int kind, int flip) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t total = (int64_t)Cout * Cin * taps;

@@ -53,6 +53,33 @@ __device__ __forceinline__ int src_row(const ConvArgs &a, int j, int t) {
 }
 
 
+// Dense-geometry source row from output coordinates (no division by the map size): same result as src_row() for modes 1 / 2.
+__device__ __forceinline__ int src_row_dense(const rd_conv_index &ix, int b, int oy, int ox, int t) {
+    const int ky = t / ix.KW, kx = t - ky * ix.KW;
+    int iy, ixx;
+    if (ix.mode == 1) {
+        iy = oy * ix.stride - ix.pad + ky;
+        ixx = ox * ix.stride - ix.pad + kx;
+    } else {
+        const int ny = oy + ix.pad - ky, nx = ox + ix.pad - kx;
+        if (ny < 0 || nx < 0) return -1;
+        if (ix.stride == 1) {
+            iy = ny;
+            ixx = nx;
+        } else if (ix.stride == 2) {
+            if ((ny | nx) & 1) return -1;
+            iy = ny >> 1;
+            ixx = nx >> 1;
+        } else {
+            if ((ny % ix.stride) || (nx % ix.stride)) return -1;
+            iy = ny / ix.stride;
+            ixx = nx / ix.stride;
+        }
+    }
+    if (iy < 0 || iy >= ix.Hin || ixx < 0 || ixx >= ix.Win) return -1;
+    return (b * ix.Hin + iy) * ix.Win + ixx;
+}
+
 // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2), so give every XCD a
 // contiguous slab of row tiles and walk (row tile, column tile) pairs in that slab consecutively: the column tiles of one row
 // tile re-use its gathered A rows from the XCD's L2, and neighbouring row tiles share their halo rows.  Placement only affects
