@@ -153,8 +153,8 @@ int rd_conv_wgrad(const float *in, int in_rows, int Cin, const float *grad_out, 
  *   kind 6: kernel layout [Cout][taps][Cin] -> [taps][Cin][Cout] (DCN column-gradient operand) */
 int rd_weight_layout(const float *src, float *dst, int Cout, int Cin, int taps, int kind, int flip, void *stream);
 
-/* column sums: out[C] = sum_j x[j][:] (bias gradients); out zeroed inside. */
-int rd_colsum(const float *x, int64_t rows, int C, float *out, float *ws, int64_t ws_bytes, void *stream);
+/* column sums: out[C] += sum_j x[j][:] (bias gradients).  ACCUMULATES with fp32 atomics: the caller zero-fills out. */
+int rd_colsum(const float *x, int64_t rows, int C, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * D. BatchNorm over rows (BatchNorm1d on sparse rows == BatchNorm2d on channels-last maps), fused with
@@ -163,7 +163,12 @@ int rd_colsum(const float *x, int64_t rows, int C, float *out, float *ws, int64_
  * ---------------------------------------------------------------------------------------------- */
 /* stats[2C] (sum, sumsq; e.g. from rd_conv_fwd or rd_bn_stats) -> mean/rstd (saved for backward), scale/shift,
  * running stats update (momentum, unbiased var), all on device.  count = number of rows. */
-int rd_bn_stats(const float *x, int64_t rows, int C, float *stats /*[2C]*/, float *ws, int64_t ws_bytes, void *stream);
+/* rd_bn_stats ACCUMULATES (sum, sumsq) into stats[2C] with fp32 atomics (one launch): the caller zero-fills stats. */
+int rd_bn_stats(const float *x, int64_t rows, int C, float *stats /*[2C]*/, void *stream);
+/* Train-mode forward in one launch: rd_bn_finalize + rd_affine_act fused (mean/rstd/scale/shift outputs may be NULL). */
+int rd_bn_train_fwd(const float *x, int64_t rows, int C, const float *stats, const float *gamma, const float *beta, float eps,
+                    float momentum, float *running_mean, float *running_var, const float *residual, int act, float *y,
+                    float *mean, float *rstd, float *scale, float *shift, void *stream);
 int rd_bn_finalize(const float *stats, int64_t rows, int C, const float *gamma, const float *beta, float eps, float momentum,
                    float *running_mean, float *running_var, float *mean, float *rstd, float *scale, float *shift, void *stream);
 /* y = x*scale + shift (+ residual) ; act: 0 none, 1 relu, 2 gelu(erf). */
@@ -171,11 +176,11 @@ int rd_affine_act(const float *x, int64_t rows, int C, const float *scale, const
                   int act, float *y, void *stream);
 /* Backward of y = act(bn(x) + residual) in train mode.  Inputs: x (pre-BN), y (output, for the ReLU mask) or
  * pre-activation recomputed for GELU, grad_y.  Outputs grad_x, grad_gamma, grad_beta, grad_residual (= masked grad_y,
- * may alias NULL).  ws: see rd_bn_bwd_ws_bytes. */
-int64_t rd_bn_bwd_ws_bytes(int64_t rows, int C);
+ * may be NULL).  grad_gamma / grad_beta are ACCUMULATED with fp32 atomics by the reduction pass and then read by the apply
+ * pass: the caller zero-fills them. */
 int rd_bn_bwd(const float *x, const float *y, const float *grad_y, int64_t rows, int C, const float *gamma,
               const float *mean, const float *rstd, const float *scale, const float *shift, int act, int has_residual,
-              float *grad_x, float *grad_res, float *grad_gamma, float *grad_beta, float *ws, int64_t ws_bytes, void *stream);
+              float *grad_x, float *grad_res, float *grad_gamma, float *grad_beta, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * E. Sparse -> dense BEV (SparseConvTensor.dense(), spconv_backbone_2d.py:299) in channels-last, and back.

@@ -58,7 +58,37 @@ class _ZeroArena:
         return out
 
 
+class _GradArena:
+    """Zero-filled accumulators that may ESCAPE as parameter gradients (weight / bias / BatchNorm gradients are accumulated with
+    atomics and handed to autograd as they are).  One fresh torch.zeros per step, sized by the previous step's demand; the arena
+    drops its reference at the next begin_step(), so the buffer lives exactly as long as some .grad still aliases it (gradient
+    accumulation over several backward passes stays correct)."""
+
+    def __init__(self):
+        self.buf = None
+        self.off = 0
+        self.high = 0
+        self.step_high = 0
+
+    def begin_step(self):
+        self.high = max(self.high, self.step_high)
+        self.buf, self.off, self.step_high = None, 0, 0
+
+    def take(self, n, device):
+        n_al = (n + 63) // 64 * 64
+        self.step_high += n_al
+        if self.buf is None and self.high > 0:
+            self.buf = torch.zeros(int(self.high * 1.05) + 4096, dtype=torch.float32, device=device)
+            self.off = 0
+        if self.buf is None or self.buf.device != device or self.off + n_al > self.buf.numel():
+            return torch.zeros(n, dtype=torch.float32, device=device)
+        out = self.buf[self.off:self.off + n]
+        self.off += n_al
+        return out
+
+
 ARENA = _ZeroArena()
+GRAD_ARENA = _GradArena()
 _CONST = {}
 
 
@@ -76,6 +106,7 @@ _BN_TOUCHED = []          # BatchNorm modules that ran in train mode this step (
 
 def begin_step(device):
     ARENA.begin_step(device)
+    GRAD_ARENA.begin_step()
     _BN_TOUCHED.clear()
 
 
@@ -91,7 +122,8 @@ def zeros_stats(n, device):
 
 
 def zeros_accum(n, device):
-    return ARENA.take(n, device)
+    """Zero-filled accumulator whose result may be returned to autograd as a gradient."""
+    return GRAD_ARENA.take(n, device)
 
 
 def kernel_weight(param, Cout, Cin, taps, kind, flip=False):
@@ -226,8 +258,7 @@ class _BNActFn(torch.autograd.Function):
         rows, C = x.shape
         if stats is None:
             stats = K.bn_stats(x)
-        mean, rstd, scale, shift = K.bn_finalize(stats, rows, C, gamma, beta, eps, momentum, running_mean, running_var)
-        y = K.affine_act(x, scale, shift, residual, act)
+        y, mean, rstd, scale, shift = K.bn_train_fwd(x, stats, gamma, beta, eps, momentum, running_mean, running_var, residual, act)
         ctx.act, ctx.has_res = act, residual is not None
         ctx.save_for_backward(x, y, gamma, mean, rstd, scale, shift)
         return y

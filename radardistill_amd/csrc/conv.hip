@@ -18,25 +18,30 @@ using namespace rd;
 
 // BT = true: the weight operand is read TRANSPOSED, B[k][n] = w[k][tap][n] with w in the forward kernel layout [K][taps][N].
 // That is the data-gradient GEMM (K = forward Cout, N = forward Cin) on the forward weights as they are: no re-layout launch.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool DEFORM, bool BT = false>
+// KBT = K step (input channels of one tap per LDS tile).  64 was tried for the 64x64 tile (longer steps against gather latency):
+// 5-10 % slower -- the doubled LDS footprint halves the resident workgroups -- so every launch uses 32.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool DEFORM, bool BT = false, int KBT = 32>
 __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int MI = WM / 32, NI = WN / 32;
-    constexpr int BP = BN / 32;  // B float4 loads per thread
-    constexpr int AP = BM / 32;  // A float4 loads per thread
+    constexpr int LDKT = KBT + 4;        // padded LDS row (floats)
+    constexpr int TPRK = KBT / 4;        // threads per tile row (one float4 each)
+    constexpr int RP = 256 / TPRK;       // tile rows covered per pass of the 256 threads
+    constexpr int BP = BN * KBT / 1024;  // B float4 loads per thread
+    constexpr int AP = BM * KBT / 1024;  // A float4 loads per thread
     static_assert(WAVES_M * WAVES_N == 4 && MI >= 1 && NI >= 1, "4 waves, each at least one 32x32 MFMA tile");
     constexpr int LDBT = BN + 4;                                     // BT: B tile stored [k][n], row stride BN + 4 floats
-    constexpr int BSZ = BT ? KB * LDBT : BN * LDK;                   // floats of one B tile
-    __shared__ __attribute__((aligned(16))) float lds[2 * (BM * LDK + BSZ)];
+    constexpr int BSZ = BT ? KBT * LDBT : BN * LDKT;                 // floats of one B tile
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM * LDKT + BSZ)];
     __shared__ int s_tapmask;
-    constexpr int BUF = BM * LDK + BSZ;  // floats per buffer: [A tile BM x 36][B tile]
+    constexpr int BUF = BM * LDKT + BSZ;  // floats per buffer: [A tile BM x (KBT + 4)][B tile]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WAVES_N, wn = wid % WAVES_N;
     int row_tile, col_tile;
     if (!xcd_tile((a.out_rows + BM - 1) / BM, (a.Cout + BN - 1) / BN, row_tile, col_tile)) return;
     const int m0 = row_tile * BM, n0 = col_tile * BN;
-    const int ld_r = tid >> 3, ld_c = (tid & 7) * 4;
+    const int ld_r = tid / TPRK, ld_c = (tid % TPRK) * 4;
 
     // ---- which taps have any source row in this tile
     if (tid == 0) s_tapmask = 0;
@@ -44,8 +49,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
     {
         int mask = 0;
         for (int p = 0; p < AP; ++p) {
-            int j = m0 + ld_r + 32 * p;
-            if ((tid & 7) == 0)
+            int j = m0 + ld_r + RP * p;
+            if ((tid % TPRK) == 0)
                 for (int t = 0; t < a.taps; ++t)
                     if (src_row(a, j, t) >= 0) mask |= 1 << t;
         }
@@ -53,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
     }
     __syncthreads();
     const int tapmask = s_tapmask;
-    const int kchunks = a.Cin / KB;
+    const int kchunks = a.Cin / KBT;
     const int n_active = __popc(tapmask);
     const int steps = n_active * kchunks;
 
@@ -72,14 +77,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
     int cur_tap = -1, tap_iter_mask = tapmask;
 
     auto load_tile = [&](int s) {
-        int kc = (s % kchunks) * KB;
+        int kc = (s % kchunks) * KBT;
         if (s % kchunks == 0) {  // next active tap
             cur_tap = __ffs(tap_iter_mask) - 1;
             tap_iter_mask &= tap_iter_mask - 1;
             if constexpr (DEFORM) {
 #pragma unroll
                 for (int p = 0; p < AP; ++p) {
-                    const int j = m0 + ld_r + 32 * p;
+                    const int j = m0 + ld_r + RP * p;
                     if (j < a.out_rows) {
                         const int64_t o = ((int64_t)j * a.taps + cur_tap) * 4;
                         sidx[p] = *reinterpret_cast<const int4 *>(a.ix.samp_idx + o);
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
                 }
             } else {
 #pragma unroll
-                for (int p = 0; p < AP; ++p) rows[p] = src_row(a, m0 + ld_r + 32 * p, cur_tap);
+                for (int p = 0; p < AP; ++p) rows[p] = src_row(a, m0 + ld_r + RP * p, cur_tap);
             }
         }
 #pragma unroll
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
                 const int idx = tid + 256 * p, kr = idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
                 if (n < a.Cout) v = *reinterpret_cast<const f32x4 *>(a.w + ((int64_t)(kc + kr) * a.taps + cur_tap) * a.Cout + n);
             } else {
-                const int n = n0 + ld_r + 32 * p;
+                const int n = n0 + ld_r + RP * p;
                 if (n < a.Cout) v = *reinterpret_cast<const f32x4 *>(a.w + ((int64_t)n * a.taps + cur_tap) * a.Cin + kc + ld_c);
             }
             rb[p] = v;
@@ -123,14 +128,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < AP; ++p) *reinterpret_cast<f32x4 *>(lds + buf * BUF + (ld_r + 32 * p) * LDK + ld_c) = ra[p];
+        for (int p = 0; p < AP; ++p) *reinterpret_cast<f32x4 *>(lds + buf * BUF + (ld_r + RP * p) * LDKT + ld_c) = ra[p];
 #pragma unroll
         for (int p = 0; p < BP; ++p) {
             if constexpr (BT) {
                 const int idx = tid + 256 * p;
-                *reinterpret_cast<f32x4 *>(lds + buf * BUF + BM * LDK + (idx / (BN / 4)) * LDBT + (idx % (BN / 4)) * 4) = rb[p];
+                *reinterpret_cast<f32x4 *>(lds + buf * BUF + BM * LDKT + (idx / (BN / 4)) * LDBT + (idx % (BN / 4)) * 4) = rb[p];
             } else {
-                *reinterpret_cast<f32x4 *>(lds + buf * BUF + BM * LDK + (ld_r + 32 * p) * LDK + ld_c) = rb[p];
+                *reinterpret_cast<f32x4 *>(lds + buf * BUF + BM * LDKT + (ld_r + RP * p) * LDKT + ld_c) = rb[p];
             }
         }
     };
@@ -144,21 +149,21 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
     for (int s = 0; s < steps; ++s) {
         const int buf = s & 1;
         if (s + 1 < steps) load_tile(s + 1);
-        const float *Ab = lds + buf * BUF + (wm * WM + fr) * LDK + 4 * fh;
-        const float *Bb = BT ? lds + buf * BUF + BM * LDK + (4 * fh) * LDBT + wn * WN + fr
-                             : lds + buf * BUF + BM * LDK + (wn * WN + fr) * LDK + 4 * fh;
+        const float *Ab = lds + buf * BUF + (wm * WM + fr) * LDKT + 4 * fh;
+        const float *Bb = BT ? lds + buf * BUF + BM * LDKT + (4 * fh) * LDBT + wn * WN + fr
+                             : lds + buf * BUF + BM * LDKT + (wn * WN + fr) * LDKT + 4 * fh;
 #pragma unroll
-        for (int kk = 0; kk < KB / 8; ++kk) {
+        for (int kk = 0; kk < KBT / 8; ++kk) {
             f32x4 af[MI], bf[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const f32x4 *>(Ab + i * 32 * LDK + kk * 8);
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const f32x4 *>(Ab + i * 32 * LDKT + kk * 8);
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 if constexpr (BT) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) bf[j][q] = Bb[(kk * 8 + q) * LDBT + j * 32];
                 } else {
-                    bf[j] = *reinterpret_cast<const f32x4 *>(Bb + j * 32 * LDK + kk * 8);
+                    bf[j] = *reinterpret_cast<const f32x4 *>(Bb + j * 32 * LDKT + kk * 8);
                 }
             }
 #pragma unroll

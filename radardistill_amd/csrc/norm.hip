@@ -1,8 +1,7 @@
 // BatchNorm over rows (channels-last), fused affine + residual + activation, their backward, column sums, and the
 // sparse <-> dense row scatter.  See include/rdamd.h sections D and E.  All kernels are HBM-bound streaming passes:
 // float4 per lane, consecutive lanes on consecutive channels of a row (rows are contiguous, so a wave covers 1 KiB).
-// Reductions are two-stage and deterministic: per-block partial column sums, then one block adds the partials in
-// double precision in a fixed order.
+// Column reductions are one launch: per-block partial sums combined with fp32 atomics (see k_colreduce).
 #include "common.hpp"
 
 using namespace rd;
@@ -18,12 +17,15 @@ __device__ __forceinline__ float gelu_grad(float z) {
     return cdf + z * pdf;
 }
 
-// Generic column reduction: F(row, c) -> (v1, v2) per element; partial[block x][2][C].  Columns are split into chunks of
-// RED_CHUNK (grid.y), so any C % 4 == 0 works (the batched CenterHead BatchNorm has C = 2688).
+// Generic column reduction: F(row, c) -> (v1, v2) per element, summed over rows into out1[C] / out2[C] (out2 may be null).
+// Each block reduces its rows in registers and LDS, then adds its partial with fp32 atomics: one contiguous run of <= 512 columns
+// per block, i.e. full-rate 256-byte atomic wave-instructions; 256 blocks x 2C floats is ~0.5 MB of atomic traffic per launch.
+// The outputs therefore ACCUMULATE (callers zero-fill) and the summation order varies from run to run in the last bits.
+// Columns are split into chunks of RED_CHUNK (grid.y), so any C % 4 == 0 works (the batched CenterHead BatchNorm has C = 2688).
 constexpr int RED_CHUNK = 512;
 
 template <class F>
-__global__ __launch_bounds__(256) void k_colreduce(int64_t rows, int C, F f, float *partial) {
+__global__ __launch_bounds__(256) void k_colreduce(int64_t rows, int C, F f, float *out1, float *out2) {
     extern __shared__ float sm[];  // [groups][2][cw] staged reduction
     const int col0 = blockIdx.y * RED_CHUNK;
     const int cw = min(RED_CHUNK, C - col0);
@@ -44,50 +46,24 @@ __global__ __launch_bounds__(256) void k_colreduce(int64_t rows, int C, F f, flo
         *reinterpret_cast<f32x4 *>(dst + cw + c4) = s2;
     }
     __syncthreads();
-    for (int i = tid; i < 2 * cw; i += 256) {
+    for (int i = tid; i < (out2 ? 2 : 1) * cw; i += 256) {
         float s = 0.f;
         for (int q = 0; q < groups; ++q) s += sm[(int64_t)q * 2 * cw + i];
-        const int which = i / cw, c = i % cw;
-        partial[((int64_t)blockIdx.x * 2 + which) * C + col0 + c] = s;
-    }
-}
-
-// Final stage: 32 columns per block; 8 row-groups of threads walk the per-block partials with coalesced 128-byte reads, sum in
-// double in a fixed order (deterministic), then combine through LDS.  Columns [0, C) go to out1, [C, 2C) to out2 (may be null).
-__global__ __launch_bounds__(256) void k_colreduce_final(const float *__restrict__ partial, int n_blocks, int C, float *out1, float *out2) {
-    __shared__ double red[8][32];
-    const int C2 = 2 * C;
-    const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
-    const int col = blockIdx.x * 32 + c;
-    double s = 0.0;
-    if (col < C2)
-        for (int b = r; b < n_blocks; b += 8) s += (double)partial[(int64_t)b * C2 + col];
-    red[r][c] = s;
-    __syncthreads();
-    if (r == 0 && col < C2) {
-        double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[k][c];
-        if (col < C) out1[col] = (float)t;
-        else if (out2) out2[col - C] = (float)t;
+        if (i < cw) atomicAdd(&out1[col0 + i], s);
+        else atomicAdd(&out2[col0 + i - cw], s);
     }
 }
 
 template <class F>
-static int colreduce(int64_t rows, int C, F f, float *out1, float *out2, float *ws, int64_t ws_bytes, hipStream_t st, const char *who) {
+static int colreduce(int64_t rows, int C, F f, float *out1, float *out2, hipStream_t st, const char *who) {
     RD_REQUIRE(C % 4 == 0 && C >= 4, "%s: C=%d must be a positive multiple of 4", who, C);
     const int cw = std::min(C, RED_CHUNK), tpr = cw / 4, groups = 256 / tpr;
     const int chunks = (int)cdiv(C, RED_CHUNK);
     int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(RED_MAX_BLOCKS, cdiv(rows, (int64_t)groups * 8)));
-    RD_REQUIRE(ws_bytes >= (int64_t)blocks * 2 * C * 4, "%s: workspace too small (%lld < %lld)", who, (long long)ws_bytes,
-               (long long)blocks * 2 * C * 4);
     size_t shm = (size_t)groups * 2 * cw * 4;
-    k_colreduce<F><<<dim3(blocks, chunks), 256, shm, st>>>(rows, C, f, ws);
-    k_colreduce_final<<<cdiv(out2 ? 2 * C : C, 32), 256, 0, st>>>(ws, blocks, C, out1, out2);
+    k_colreduce<F><<<dim3(blocks, chunks), 256, shm, st>>>(rows, C, f, out1, out2);
     return check_launch(who);
 }
-
-extern "C" int64_t rd_bn_bwd_ws_bytes(int64_t rows, int C) { return (int64_t)RED_MAX_BLOCKS * 2 * C * 4 + 2 * C * 4; }
 
 struct StatsF {
     const float *x;
@@ -98,12 +74,9 @@ struct StatsF {
     }
 };
 
-extern "C" int rd_bn_stats(const float *x, int64_t rows, int C, float *stats, float *ws, int64_t ws_bytes, void *stream) {
-    if (rows <= 0) {
-        RD_HIP(hipMemsetAsync(stats, 0, (size_t)2 * C * 4, S(stream)));
-        return RD_OK;
-    }
-    return colreduce(rows, C, StatsF{x, C}, stats, stats + C, ws, ws_bytes, S(stream), "rd_bn_stats");
+extern "C" int rd_bn_stats(const float *x, int64_t rows, int C, float *stats, void *stream) {
+    if (rows <= 0) return RD_OK;
+    return colreduce(rows, C, StatsF{x, C}, stats, stats + C, S(stream), "rd_bn_stats");
 }
 
 struct ColsumF {
@@ -114,13 +87,9 @@ struct ColsumF {
         b = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 };
-extern "C" int rd_colsum(const float *x, int64_t rows, int C, float *out, float *ws, int64_t ws_bytes, void *stream) {
-    hipStream_t st = S(stream);
-    if (rows <= 0) {
-        RD_HIP(hipMemsetAsync(out, 0, (size_t)C * 4, st));
-        return RD_OK;
-    }
-    return colreduce(rows, C, ColsumF{x, C}, out, nullptr, ws, ws_bytes, st, "rd_colsum");
+extern "C" int rd_colsum(const float *x, int64_t rows, int C, float *out, void *stream) {
+    if (rows <= 0) return RD_OK;
+    return colreduce(rows, C, ColsumF{x, C}, out, nullptr, S(stream), "rd_colsum");
 }
 
 __global__ void k_bn_finalize(const float *stats, float n, int C, const float *gamma, const float *beta, float eps, float momentum,
@@ -180,6 +149,80 @@ extern "C" int rd_affine_act(const float *x, int64_t rows, int C, const float *s
     return check_launch("rd_affine_act");
 }
 
+// Train-mode BatchNorm forward in ONE launch: every thread derives scale/shift of its 4 channels from the batch sums (a few
+// double operations, channels stay fixed over the grid-stride loop when the stride is a multiple of C/4), block 0 also writes
+// mean / rstd / scale / shift for the backward pass and updates the running statistics.
+__global__ void k_bn_train_fwd(const float *__restrict__ x, int64_t n4, int C, const float *__restrict__ stats, float n,
+                               const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float momentum,
+                               float *running_mean, float *running_var, const float *__restrict__ residual, int act, float *__restrict__ y,
+                               float *mean_out, float *rstd_out, float *scale_out, float *shift_out) {
+    auto channel = [&](int c, float &sc, float &sh, float &mean_f, float &rstd_f, double &var_d) {
+        const double mean = (double)stats[c] / n;
+        double var = (double)stats[C + c] / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        rstd_f = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        sc = g * rstd_f;
+        mean_f = (float)mean;
+        sh = b - mean_f * sc;
+        var_d = var;
+    };
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            float sc, sh, m, r;
+            double var;
+            channel(c, sc, sh, m, r, var);
+            if (mean_out) mean_out[c] = m;
+            if (rstd_out) rstd_out[c] = r;
+            if (scale_out) scale_out[c] = sc;
+            if (shift_out) shift_out[c] = sh;
+            if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+            if (running_var) {
+                const double unbiased = n > 1.f ? var * n / (n - 1.0) : var;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+            }
+        }
+    }
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const bool fixed = (stride * 4) % C == 0;
+    f32x4 sc4, sh4;
+    int c_prev = -1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const int c = (int)((i * 4) % C);
+        if (!fixed || c_prev < 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float m, r, a_, b_;
+                double var;
+                channel(c + k, a_, b_, m, r, var);
+                sc4[k] = a_;
+                sh4[k] = b_;
+            }
+            c_prev = c;
+        }
+        f32x4 v = reinterpret_cast<const f32x4 *>(x)[i] * sc4 + sh4;
+        if (residual) v += reinterpret_cast<const f32x4 *>(residual)[i];
+        if (act == 1) {
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        } else if (act == 2) {
+            for (int k = 0; k < 4; ++k) v[k] = gelu_f(v[k]);
+        }
+        reinterpret_cast<f32x4 *>(y)[i] = v;
+    }
+}
+
+extern "C" int rd_bn_train_fwd(const float *x, int64_t rows, int C, const float *stats, const float *gamma, const float *beta, float eps,
+                               float momentum, float *running_mean, float *running_var, const float *residual, int act, float *y,
+                               float *mean, float *rstd, float *scale, float *shift, void *stream) {
+    RD_REQUIRE(rows > 0, "rd_bn_train_fwd: BatchNorm over zero rows");
+    RD_REQUIRE(C % 4 == 0 && act >= 0 && act <= 2, "rd_bn_train_fwd: C=%d must be a multiple of 4, act in 0..2", C);
+    const int64_t n4 = rows * C / 4;
+    const int blocks = (int)std::min<int64_t>(cdiv(n4, 256), 4096);
+    k_bn_train_fwd<<<blocks, 256, 0, S(stream)>>>(x, n4, C, stats, (float)rows, gamma, beta, eps, momentum, running_mean, running_var, residual,
+                                                  act, y, mean, rstd, scale, shift);
+    return check_launch("rd_bn_train_fwd");
+}
+
 // ---- backward of y = act(x*scale + shift [+ residual]) with train-mode batch statistics
 //   g' = grad_y * act'(.)          (relu: y > 0; gelu: derivative at z = x*scale + shift; residual excluded for gelu)
 //   dbeta = sum g', dgamma = sum g' * xhat, xhat = (x - mean) * rstd
@@ -230,14 +273,13 @@ __global__ void k_bn_bwd_apply(const float *__restrict__ x, const float *__restr
 
 extern "C" int rd_bn_bwd(const float *x, const float *y, const float *grad_y, int64_t rows, int C, const float *gamma, const float *mean,
                          const float *rstd, const float *scale, const float *shift, int act, int has_residual, float *grad_x,
-                         float *grad_res, float *grad_gamma, float *grad_beta, float *ws, int64_t ws_bytes, void *stream) {
+                         float *grad_res, float *grad_gamma, float *grad_beta, void *stream) {
     RD_REQUIRE(rows > 0, "rd_bn_bwd: zero rows");
     RD_REQUIRE(act >= 0 && act <= 2, "rd_bn_bwd: bad act");
     RD_REQUIRE(!(act == 2 && has_residual), "rd_bn_bwd: gelu with residual is not supported");
-    RD_REQUIRE(ws_bytes >= rd_bn_bwd_ws_bytes(rows, C), "rd_bn_bwd: workspace too small");
+    RD_REQUIRE(grad_gamma && grad_beta, "rd_bn_bwd: grad_gamma / grad_beta are required (zero-filled by the caller; the apply kernel reads them)");
     hipStream_t st = S(stream);
-    RD_REQUIRE(grad_gamma && grad_beta, "rd_bn_bwd: grad_gamma / grad_beta are required (the apply kernel reads them)");
-    int rc = colreduce(rows, C, BnBwdF{x, y, grad_y, mean, rstd, scale, shift, C, act}, grad_beta, grad_gamma, ws, ws_bytes, st, "rd_bn_bwd");
+    int rc = colreduce(rows, C, BnBwdF{x, y, grad_y, mean, rstd, scale, shift, C, act}, grad_beta, grad_gamma, st, "rd_bn_bwd");
     if (rc) return rc;
     int64_t n4 = rows * C / 4;
     int blocks = (int)std::min<int64_t>(cdiv(n4, 256), 4096);

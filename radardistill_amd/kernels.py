@@ -269,19 +269,15 @@ def weight_layout(src, Cout, Cin, taps, kind, flip=False, out_shape=None):
     return dst
 
 
-def _red_ws(rows, C, device):
-    nbytes = native.lib().rd_bn_bwd_ws_bytes(int(rows), int(C))
-    return torch.empty(nbytes // 4, dtype=f32, device=device), nbytes
-
-
 def colsum(x):
+    """Column sums (bias gradients): one launch, per-block partials combined with fp32 atomics into a zero-filled output."""
     _chk(x, f32, "colsum input", 2)
     rows, C = x.shape
-    out = torch.empty(C, dtype=f32, device=x.device)
     if C % 4 != 0:       # tiny heads (1..3 channels): not worth a kernel variant
         raise RuntimeError("colsum: C must be a multiple of 4")
-    ws, nb = _red_ws(rows, C, x.device)
-    check(native.lib().rd_colsum(_p(x), rows, C, _p(out), _p(ws), nb, _stream()), "rd_colsum")
+    from . import autograd as _A
+    out = _A.zeros_accum(C, x.device)
+    check(native.lib().rd_colsum(_p(x), rows, C, _p(out), _stream()), "rd_colsum")
     return out
 
 
@@ -289,10 +285,28 @@ def colsum(x):
 def bn_stats(x):
     _chk(x, f32, "bn input", 2)
     rows, C = x.shape
-    stats = torch.empty(2 * C, dtype=f32, device=x.device)
-    ws, nb = _red_ws(rows, C, x.device)
-    check(native.lib().rd_bn_stats(_p(x), rows, C, _p(stats), _p(ws), nb, _stream()), "rd_bn_stats")
+    from . import autograd as _A
+    stats = _A.zeros_stats(2 * C, x.device)
+    check(native.lib().rd_bn_stats(_p(x), rows, C, _p(stats), _stream()), "rd_bn_stats")
     return stats
+
+
+def bn_train_fwd(x, stats, gamma, beta, eps, momentum, running_mean, running_var, residual, act):
+    """finalize + affine + residual + activation in one launch -> y, (mean, rstd, scale, shift) for the backward pass."""
+    _chk(x, f32, "bn input", 2)
+    rows, C = x.shape
+    if _chk(stats, f32, "bn stats").numel() != 2 * C:
+        raise RuntimeError("bn_train_fwd: stats must hold 2*C sums")
+    if residual is not None and _chk(residual, f32, "residual", 2).shape != x.shape:
+        raise RuntimeError("bn_train_fwd: residual shape mismatch")
+    for t, nm in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
+        if t is not None and _chk(t, f32, nm).numel() != C:
+            raise RuntimeError(f"bn_train_fwd: {nm} must have {C} elements")
+    side = torch.empty((4, C), dtype=f32, device=x.device)
+    y = torch.empty_like(x)
+    check(native.lib().rd_bn_train_fwd(_p(x), rows, C, _p(stats), _p(gamma), _p(beta), eps, momentum, _p(running_mean), _p(running_var),
+                                       _p(residual), act, _p(y), _p(side[0]), _p(side[1]), _p(side[2]), _p(side[3]), _stream()), "rd_bn_train_fwd")
+    return y, side[0], side[1], side[2], side[3]
 
 
 def bn_finalize(stats, rows, C, gamma, beta, eps, momentum, running_mean, running_var):
@@ -325,11 +339,11 @@ def bn_bwd(x, y, grad_y, gamma, mean, rstd, scale, shift, act, has_residual):
         raise RuntimeError("bn_bwd: shape mismatch")
     gx = torch.empty_like(x)
     gres = torch.empty_like(x) if has_residual else None
-    gg = torch.empty(C, dtype=f32, device=x.device)
-    gb = torch.empty(C, dtype=f32, device=x.device)
-    ws, nb = _red_ws(rows, C, x.device)
+    from . import autograd as _A
+    g2 = _A.zeros_accum(2 * C, x.device)            # [grad_gamma | grad_beta], accumulated by the reduction pass
+    gg, gb = g2[:C], g2[C:]
     check(native.lib().rd_bn_bwd(_p(x), _p(y), _p(grad_y), rows, C, _p(gamma), _p(mean), _p(rstd), _p(scale), _p(shift), act,
-                                 int(has_residual), _p(gx), _p(gres), _p(gg), _p(gb), _p(ws), nb, _stream()), "rd_bn_bwd")
+                                 int(has_residual), _p(gx), _p(gres), _p(gg), _p(gb), _stream()), "rd_bn_bwd")
     return gx, gres, gg, gb
 
 

@@ -56,12 +56,12 @@ SIGNATURES = {
     "rd_conv_dgrad": (c_int, [_P, c_int, c_int, _P, c_int, _P, c_int, c_int, ctypes.POINTER(ConvIndex), _P]),
     "rd_conv_wgrad": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, ctypes.POINTER(ConvIndex), _P, _P]),
     "rd_weight_layout": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
-    "rd_colsum": (c_int, [_P, c_i64, c_int, _P, _P, c_i64, _P]),
-    "rd_bn_stats": (c_int, [_P, c_i64, c_int, _P, _P, c_i64, _P]),
+    "rd_colsum": (c_int, [_P, c_i64, c_int, _P, _P]),
+    "rd_bn_stats": (c_int, [_P, c_i64, c_int, _P, _P]),
+    "rd_bn_train_fwd": (c_int, [_P, c_i64, c_int, _P, _P, _P, c_f32, c_f32, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P]),
     "rd_bn_finalize": (c_int, [_P, c_i64, c_int, _P, _P, c_f32, c_f32, _P, _P, _P, _P, _P, _P, _P]),
     "rd_affine_act": (c_int, [_P, c_i64, c_int, _P, _P, _P, c_int, _P, _P]),
-    "rd_bn_bwd_ws_bytes": (c_i64, [c_i64, c_int]),
-    "rd_bn_bwd": (c_int, [_P, _P, _P, c_i64, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, c_i64, _P]),
+    "rd_bn_bwd": (c_int, [_P, _P, _P, c_i64, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "rd_rows_to_dense": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "rd_dense_to_rows": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "rd_dcn_prep": (c_int, [_P, c_int, _P, c_int, c_int] + [c_int] * 10 + [_P, _P, _P]),
