@@ -247,6 +247,8 @@ static int validate_index(const rd_conv_index *ix, int taps, int in_rows, int ou
 // 0 = exact fp32 MFMA (default), 1 = bf16x3 split MFMA (conv_b3.hip)
 static int g_conv_math = 0;
 int launch_conv_b3(const ConvArgs &a, int mode, hipStream_t st);
+int launch_wgrad_b3(const float *in, int in_rows, int Cin, const float *go, int out_rows, int Cout, int taps, const rd_conv_index *idx, float *gw,
+                    int rows_per_block, int64_t chunks, int tiles, hipStream_t st);
 extern "C" int rd_set_conv_math(int mode) {
     RD_REQUIRE(mode == 0 || mode == 1, "rd_set_conv_math: mode must be 0 (f32) or 1 (bf16x3)");
     g_conv_math = mode;
@@ -565,9 +567,13 @@ extern "C" int rd_conv_wgrad(const float *in, int in_rows, int Cin, const float 
     }
     int rows_per_block = (int)(cdiv(cdiv(out_rows, chunks), WG_KB) * WG_KB);
     chunks = cdiv(out_rows, rows_per_block);
+    hipStream_t st = S(stream);
+    if (g_conv_math == 1 && wide) {   // bf16x3: the 128x128-tile split-bf16 kernel (conv_b3.hip); narrow shapes stay exact fp32
+        launch_wgrad_b3(in, in_rows, Cin, grad_out, out_rows, Cout, taps, idx, grad_wk, rows_per_block, chunks, tiles, st);
+        return check_launch("rd_conv_wgrad(bf16x3)");
+    }
     WgradArgs a{in, in_rows, Cin, grad_out, out_rows, Cout, taps, *idx, grad_wk, rows_per_block};
     dim3 grid((unsigned)chunks, (unsigned)tiles);
-    hipStream_t st = S(stream);
     if (idx->mode == 3) {
         if (wide) k_conv_wgrad<true, 128><<<grid, 256, 0, st>>>(a);
         else k_conv_wgrad<true, 64><<<grid, 256, 0, st>>>(a);

@@ -243,3 +243,206 @@ int launch_conv_b3(const ConvArgs &a, int mode, hipStream_t st) {
     }
     return RD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- weight gradient, bf16x3
+// Same contract as k_conv_wgrad (conv.hip): grad_w[n][t][c] += sum_j grad_out[j][n] * in[src(j,t)][c], 128 (Cout) x 128 (Cin)
+// tile of one tap per workgroup, K = rows in steps of 32, row chunks combined with fp32 atomics.
+// Both operands arrive k-major (rows x channels) but the 32x32x16 bf16 MFMA wants 8 consecutive k per lane, so every thread
+// loads a 4 (rows) x 4 (channels) block, splits it into bf16 hi/lo, transposes it in registers and writes 4 k-contiguous
+// 8-byte pieces into [channel][k] LDS images (80-byte rows, read back as 16-byte fragments exactly like the forward kernel).
+// Loader map: k-group g = tid & 7 (rows 4g..4g+3), channel quad q = tid >> 3: a wave's load of one row offset covers 8 rows x
+// 128 contiguous bytes; its LDS writes are 2-way bank conflicted at worst.
+struct WgradArgsB3 {
+    const float *in;
+    int in_rows, Cin;
+    const float *go;
+    int out_rows, Cout, taps;
+    rd_conv_index ix;
+    float *gw;
+    int rows_per_block;
+};
+
+template <bool DEFORM>
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad_b3(const WgradArgsB3 a) {
+    constexpr int T = 128;                       // tile edge (Cout and Cin)
+    __shared__ __attribute__((aligned(16))) __bf16 lds[4 * T * LDB];   // [G hi][G lo][X hi][X lo], each [128 channels][40]
+    __shared__ int s_any;
+    __bf16 *Gh = lds, *Gl = Gh + T * LDB, *Xh = Gl + T * LDB, *Xl = Xh + T * LDB;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int tile = blockIdx.y;
+    const int n_nt = (a.Cin + T - 1) / T, n_mt = (a.Cout + T - 1) / T;
+    const int t = tile / (n_mt * n_nt);
+    const int mt = (tile / n_nt) % n_mt, nt = tile % n_nt;
+    const int co0 = mt * T, ci0 = nt * T;
+    const int r_begin = blockIdx.x * a.rows_per_block;
+    const int r_end = min(a.out_rows, r_begin + a.rows_per_block);
+    const int n_steps = (r_end - r_begin + KB3 - 1) / KB3;
+    const int g = tid & 7, q = tid >> 3;         // rows 4g..4g+3 of the step, channels 4q..4q+3 of the tile
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // dense geometry: a (b, oy, ox) cursor at this thread's first row of the step, advanced without divisions
+    const bool dense = a.ix.mode == 1 || a.ix.mode == 2;
+    int cb = 0, cy = 0, cx = 0;
+    if (dense) {
+        const int j = r_begin + 4 * g;
+        cx = j % a.ix.Wout;
+        cy = (j / a.ix.Wout) % a.ix.Hout;
+        cb = j / (a.ix.Wout * a.ix.Hout);
+    }
+    auto advance = [&](int &b, int &y, int &x, int n) {
+        x += n;
+        while (x >= a.ix.Wout) {
+            x -= a.ix.Wout;
+            if (++y == a.ix.Hout) {
+                y = 0;
+                ++b;
+            }
+        }
+    };
+
+    f32x4 rg[4], rx[4];
+    int any_next = 0;
+    auto load_tile = [&](int s) {
+        const int r0 = r_begin + s * KB3 + 4 * g;
+        any_next = 0;
+        int b = cb, y = cy, x = cx;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = r0 + e;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (DEFORM) {
+                if (j < r_end) {
+                    const int64_t o = ((int64_t)j * a.taps + t) * 4;
+                    const int4 c4 = *reinterpret_cast<const int4 *>(a.ix.samp_idx + o);
+                    if (max(max(c4.x, c4.y), max(c4.z, c4.w)) >= 0) {
+                        any_next = 1;
+                        if (ci0 + 4 * q < a.Cin) {
+                            const f32x4 w = *reinterpret_cast<const f32x4 *>(a.ix.samp_w + o);
+                            const float *base = a.in + ci0 + 4 * q;
+                            if (c4.x >= 0) v += w[0] * *reinterpret_cast<const f32x4 *>(base + (int64_t)c4.x * a.Cin);
+                            if (c4.y >= 0) v += w[1] * *reinterpret_cast<const f32x4 *>(base + (int64_t)c4.y * a.Cin);
+                            if (c4.z >= 0) v += w[2] * *reinterpret_cast<const f32x4 *>(base + (int64_t)c4.z * a.Cin);
+                            if (c4.w >= 0) v += w[3] * *reinterpret_cast<const f32x4 *>(base + (int64_t)c4.w * a.Cin);
+                        }
+                    }
+                }
+            } else {
+                int src = -1;
+                if (j < r_end) {
+                    if (dense) {
+                        src = src_row_dense(a.ix, b, y, x, t);
+                    } else {
+                        ConvArgs c;
+                        c.out_rows = a.out_rows;
+                        c.taps = a.taps;
+                        c.ix = a.ix;
+                        src = src_row(c, j, t);
+                    }
+                }
+                if (dense) advance(b, y, x, 1);
+                if (src >= 0) {
+                    any_next = 1;
+                    if (ci0 + 4 * q < a.Cin) v = *reinterpret_cast<const f32x4 *>(a.in + (int64_t)src * a.Cin + ci0 + 4 * q);
+                }
+            }
+            rx[e] = v;
+            f32x4 u = {0.f, 0.f, 0.f, 0.f};
+            if (j < r_end) {
+                const int co = co0 + 4 * q;
+                const float *src = a.go + (int64_t)j * a.Cout + co;
+                if (co + 3 < a.Cout && (a.Cout & 3) == 0) u = *reinterpret_cast<const f32x4 *>(src);
+                else {
+                    if (co + 0 < a.Cout) u[0] = src[0];
+                    if (co + 1 < a.Cout) u[1] = src[1];
+                    if (co + 2 < a.Cout) u[2] = src[2];
+                    if (co + 3 < a.Cout) u[3] = src[3];
+                }
+            }
+            rg[e] = u;
+        }
+        if (dense) advance(cb, cy, cx, KB3);
+    };
+    // 4x4 register transpose + hi/lo split: element (row e, channel c) -> piece of channel c holding rows 0..3
+    auto store_block = [&](const f32x4 (&blk)[4], __bf16 *hi_img, __bf16 *lo_img) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = blk[e][c];
+                const __bf16 h = (__bf16)v;
+                hi[e] = h;
+                lo[e] = (__bf16)(v - (float)h);
+            }
+            *reinterpret_cast<bf16x4 *>(hi_img + (4 * q + c) * LDB + 4 * g) = hi;
+            *reinterpret_cast<bf16x4 *>(lo_img + (4 * q + c) * LDB + 4 * g) = lo;
+        }
+    };
+
+    if (tid == 0) s_any = 0;
+    if (n_steps > 0) load_tile(0);
+    const int fr = lane & 31, fh = lane >> 5;
+    for (int s = 0; s < n_steps; ++s) {
+        __syncthreads();                          // previous step's fragment reads are done
+        store_block(rg, Gh, Gl);
+        store_block(rx, Xh, Xl);
+        if (any_next) s_any = s + 1;              // tag = step index + 1: no reset pass needed
+        __syncthreads();
+        const bool any = s_any == s + 1;
+        if (s + 1 < n_steps) load_tile(s + 1);    // global loads of the next step fly under this step's MFMAs
+        if (any) {
+            const __bf16 *Ah = Gh + (wm * 64 + fr) * LDB + 8 * fh;
+            const __bf16 *Bh = Xh + (wn * 64 + fr) * LDB + 8 * fh;
+#pragma unroll
+            for (int ks = 0; ks < KB3 / 16; ++ks) {
+                bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ah[i] = *reinterpret_cast<const bf16x8 *>(Ah + i * 32 * LDB + ks * 16);
+                    al[i] = *reinterpret_cast<const bf16x8 *>(Ah + T * LDB + i * 32 * LDB + ks * 16);
+                    bh[i] = *reinterpret_cast<const bf16x8 *>(Bh + i * 32 * LDB + ks * 16);
+                    bl[i] = *reinterpret_cast<const bf16x8 *>(Bh + T * LDB + i * 32 * LDB + ks * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ci = ci0 + wn * 64 + j * 32 + fr;
+        if (ci < a.Cin) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    const float v = acc[i][j][r];
+                    if (co < a.Cout && v != 0.f) atomicAdd(&a.gw[((int64_t)co * a.taps + t) * a.Cin + ci], v);
+                }
+        }
+    }
+}
+
+int launch_wgrad_b3(const float *in, int in_rows, int Cin, const float *go, int out_rows, int Cout, int taps, const rd_conv_index *idx, float *gw,
+                    int rows_per_block, int64_t chunks, int tiles, hipStream_t st) {
+    WgradArgsB3 a{in, in_rows, Cin, go, out_rows, Cout, taps, *idx, gw, rows_per_block};
+    dim3 grid((unsigned)chunks, (unsigned)tiles);
+    if (idx->mode == 3) k_conv_wgrad_b3<true><<<grid, 256, 0, st>>>(a);
+    else k_conv_wgrad_b3<false><<<grid, 256, 0, st>>>(a);
+    return RD_OK;
+}
