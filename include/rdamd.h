@@ -132,7 +132,7 @@ int rd_get_conv_math(void);
 /* Data gradient on the forward weights: grad_in[i][c] = sum_t sum_n grad_out[src_bwd(i,t)][n] * weight_k[n][t][c], with weight_k the
  * FORWARD kernel layout [Cout][taps][Cin] (the kernel reads it transposed; no re-laid-out copy) and idx the backward index
  * (transposed neighbour table / flip = 1 for sub-manifold, the transposed geometry for dense convolutions).  Cout % 32 == 0
- * (zero-pad narrower outputs and use rd_conv_fwd), Cin % 4 == 0; exact-fp32 mode only.
+ * (zero-pad narrower outputs and use rd_conv_fwd), Cin % 4 == 0; follows rd_set_conv_math like rd_conv_fwd.
  * Replaces spconv's backward-data implicit GEMM and cuDNN's conv backward-data (autograd of spconv_backbone_2d.py / Conv2d). */
 int rd_conv_dgrad(const float *grad_out, int out_rows, int Cout, const float *weight_k, int taps, float *grad_in, int in_rows, int Cin,
                   const rd_conv_index *idx, void *stream);

@@ -207,6 +207,9 @@ class _ConvFn(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             wk = ctx.wk
+            # exact fp32: the kernel reads the forward weights transposed (no re-layout launch).  bf16x3: the transposed read costs
+            # a register transpose per weight tile and measured ~1 ms/step slower than re-laying the weights out once, so that
+            # mode keeps the [Cin][taps][Cout] copy (rd_conv_dgrad itself works in both modes).
             if Cout % 32 == 0 and K.get_conv_math() == "f32":
                 gx = K.conv_dgrad(grad_out, wk, spec.taps, spec.in_rows, Cin, spec.bwd_ix, nbr_keepalive=spec.bwd_nbr)   # forward weights, read transposed
             else:

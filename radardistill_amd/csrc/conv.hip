@@ -247,6 +247,7 @@ static int validate_index(const rd_conv_index *ix, int taps, int in_rows, int ou
 // 0 = exact fp32 MFMA (default), 1 = bf16x3 split MFMA (conv_b3.hip)
 static int g_conv_math = 0;
 int launch_conv_b3(const ConvArgs &a, int mode, hipStream_t st);
+int launch_dgrad_b3(const ConvArgs &a, hipStream_t st);
 int launch_wgrad_b3(const float *in, int in_rows, int Cin, const float *go, int out_rows, int Cout, int taps, const rd_conv_index *idx, float *gw,
                     int rows_per_block, int64_t chunks, int tiles, hipStream_t st);
 extern "C" int rd_set_conv_math(int mode) {
@@ -311,7 +312,6 @@ extern "C" int rd_conv_dgrad(const float *grad_out, int out_rows, int Cout, cons
                              int Cin, const rd_conv_index *idx, void *stream) {
     RD_REQUIRE(Cout > 0 && Cout % KB == 0, "rd_conv_dgrad: Cout=%d must be a multiple of %d (zero-pad narrow outputs)", Cout, KB);
     RD_REQUIRE(Cin > 0 && Cin % 4 == 0 && in_rows >= 0 && out_rows >= 0, "rd_conv_dgrad: bad sizes");
-    RD_REQUIRE(g_conv_math == 0, "rd_conv_dgrad: exact-fp32 mode only (bf16x3 uses rd_weight_layout(kind 2) + rd_conv_fwd)");
     RD_REQUIRE(idx && idx->mode != 3, "rd_conv_dgrad: deformable sampling has its own data gradient (rd_dcn_bwd_data)");
     int rc = validate_index(idx, taps, out_rows, in_rows, "rd_conv_dgrad");
     if (rc) return rc;
@@ -320,6 +320,10 @@ extern "C" int rd_conv_dgrad(const float *grad_out, int out_rows, int Cout, cons
     ConvArgs a{grad_out, out_rows, Cout, weight_k, taps, nullptr, grad_in, in_rows, Cin, *idx, nullptr, nullptr, nullptr, 0, nullptr};
     hipStream_t st = S(stream);
     dim3 block(256);
+    if (g_conv_math == 1 && Cin > 32) {
+        launch_dgrad_b3(a, st);
+        return check_launch("rd_conv_dgrad(bf16x3)");
+    }
     const int64_t big_blocks = cdiv(in_rows, 128) * cdiv(Cin, 128);
     if (Cin > 64) {
         if (big_blocks >= 384) k_conv_igemm<128, 128, 2, 2, false, true><<<dim3(xcd_grid(cdiv(in_rows, 128), cdiv(Cin, 128))), block, 0, st>>>(a);

@@ -9,7 +9,7 @@
 // v_mfma_f32_32x32x2_f32: 3 passes still cost 5.3x fewer matrix-pipe cycles than exact fp32.
 //
 // Tile: BM x BN output, K step 32 input channels of one tap (two k16 MFMA steps), 4 waves (2 x 2).  LDS image per operand and
-// part: [rows][40] bf16 (80-byte rows: a 16-lane ds_read_b128 group covers all 64 banks once).  Lane l reads A[row l&31]
+// part: [rows][32] bf16, 16-byte chunks XOR-swizzled by the row (a 16-lane ds_read_b128 group covers all 64 banks once).  Lane l reads A[row l&31]
 // [k = 8*(l>>5) + 0..7] as one 16-byte fragment (the 32x32x16 bf16 operand map).
 #include "conv_common.hpp"
 
@@ -30,14 +30,19 @@ __device__ __forceinline__ void split4(const f32x4 v, bf16x4 &hi, bf16x4 &lo) {
     }
 }
 
-template <int BM, int BN, bool DEFORM>
+// BT = true: data gradient on the forward weights, B[k][n] = w[k][tap][n] (see k_conv_igemm in conv.hip).  The weight tile then
+// arrives n-contiguous; every thread takes a 4 (k) x 4 (n) block, transposes it in registers and writes k-contiguous pieces.
+template <int BM, int BN, bool DEFORM, bool BT = false>
 __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int MI = WM / 32, NI = WN / 32;
     constexpr int AP = BM / 32, BP = BN / 32;
     static_assert(MI >= 1 && NI >= 1, "wave tile at least 32x32");
-    // per buffer: [A hi BM rows][A lo][B hi BN rows][B lo], 80 bytes per row
-    constexpr int BUF = 2 * (BM + BN) * LDB;  // bf16 elements per buffer
+    // per buffer: [A hi BM rows][A lo][B hi BN rows][B lo]; UNPADDED 64-byte rows (32 bf16) with the 16-byte chunk index XOR-ed
+    // by (row >> 2) & 3: a 16-lane ds_read_b128 group (16 rows, one chunk) still covers all 64 banks once, and the 128x128 tile
+    // needs 64 KiB instead of 80 KiB of LDS, so two workgroups fit one CU
+    constexpr int LDS_ROW = KB3;                  // bf16 elements per row
+    constexpr int BUF = 2 * (BM + BN) * LDS_ROW;  // bf16 elements per buffer
     __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BUF];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -75,7 +80,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[AP], rb[BP];
+    f32x4 ra[AP], rb[BT ? 1 : BP], rbt[BT ? 4 : 1];
+    const int bt_g = tid & 7, bt_q = tid >> 3;   // BT loader: k rows 4 bt_g .. +3, weight columns 4 bt_q .. +3
     int rows[AP];
     int4 sidx[DEFORM ? AP : 1];
     f32x4 sw[DEFORM ? AP : 1];
@@ -117,29 +123,57 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
             }
             ra[p] = v;
         }
+        if constexpr (BT) {
+            const int n = n0 + 4 * bt_q;
 #pragma unroll
-        for (int p = 0; p < BP; ++p) {
-            const int n = n0 + ld_r + 32 * p;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n < a.Cout) v = *reinterpret_cast<const f32x4 *>(a.w + ((int64_t)n * a.taps + cur_tap) * a.Cin + kc + ld_c);
-            rb[p] = v;
+            for (int e = 0; e < 4; ++e) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (bt_q < BN / 4 && n < a.Cout)
+                    v = *reinterpret_cast<const f32x4 *>(a.w + ((int64_t)(kc + 4 * bt_g + e) * a.taps + cur_tap) * a.Cout + n);
+                rbt[e] = v;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < BP; ++p) {
+                const int n = n0 + ld_r + 32 * p;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (n < a.Cout) v = *reinterpret_cast<const f32x4 *>(a.w + ((int64_t)n * a.taps + cur_tap) * a.Cin + kc + ld_c);
+                rb[p] = v;
+            }
         }
     };
     auto store_tile = [&](int buf) {
-        __bf16 *Ah = lds + buf * BUF, *Al = Ah + BM * LDB, *Bh = Al + BM * LDB, *Bl = Bh + BN * LDB;
+        __bf16 *Ah = lds + buf * BUF, *Al = Ah + BM * LDS_ROW, *Bh = Al + BM * LDS_ROW, *Bl = Bh + BN * LDS_ROW;
+        // element offset of this thread's 4 k-values in a row: chunk (ld_c >> 3) swizzled by the row, half-chunk ld_c & 4
+        auto off = [&](int row) { return row * LDS_ROW + ((((ld_c >> 3) ^ (row >> 2)) & 3) << 3) + (ld_c & 4); };
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
             bf16x4 hi, lo;
             split4(ra[p], hi, lo);
-            *reinterpret_cast<bf16x4 *>(Ah + (ld_r + 32 * p) * LDB + ld_c) = hi;
-            *reinterpret_cast<bf16x4 *>(Al + (ld_r + 32 * p) * LDB + ld_c) = lo;
+            *reinterpret_cast<bf16x4 *>(Ah + off(ld_r + 32 * p)) = hi;
+            *reinterpret_cast<bf16x4 *>(Al + off(ld_r + 32 * p)) = lo;
         }
+        if constexpr (BT) {
+            if (bt_q < BN / 4) {
 #pragma unroll
-        for (int p = 0; p < BP; ++p) {
-            bf16x4 hi, lo;
-            split4(rb[p], hi, lo);
-            *reinterpret_cast<bf16x4 *>(Bh + (ld_r + 32 * p) * LDB + ld_c) = hi;
-            *reinterpret_cast<bf16x4 *>(Bl + (ld_r + 32 * p) * LDB + ld_c) = lo;
+                for (int c = 0; c < 4; ++c) {          // column c of the 4x4 block: 4 consecutive k of weight row n = 4 bt_q + c
+                    const f32x4 col = {rbt[0][c], rbt[1][c], rbt[2][c], rbt[3][c]};
+                    bf16x4 hi, lo;
+                    split4(col, hi, lo);
+                    const int row = 4 * bt_q + c;
+                    const int o = row * LDS_ROW + ((((bt_g >> 1) ^ (row >> 2)) & 3) << 3) + ((bt_g & 1) << 2);
+                    *reinterpret_cast<bf16x4 *>(Bh + o) = hi;
+                    *reinterpret_cast<bf16x4 *>(Bl + o) = lo;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < BP; ++p) {
+                bf16x4 hi, lo;
+                split4(rb[p], hi, lo);
+                *reinterpret_cast<bf16x4 *>(Bh + off(ld_r + 32 * p)) = hi;
+                *reinterpret_cast<bf16x4 *>(Bl + off(ld_r + 32 * p)) = lo;
+            }
         }
     };
 
@@ -152,22 +186,26 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
     for (int s = 0; s < steps; ++s) {
         const int buf = s & 1;
         if (s + 1 < steps) load_tile(s + 1);
-        const __bf16 *Ah = lds + buf * BUF + (wm * WM + fr) * LDB + 8 * fh;
-        const __bf16 *Al = Ah + BM * LDB;
-        const __bf16 *Bh = lds + buf * BUF + 2 * BM * LDB + (wn * WN + fr) * LDB + 8 * fh;
-        const __bf16 *Bl = Bh + BN * LDB;
+        // fragment of lane (row fr, k = 16 ks + 8 fh .. +7) = chunk 2 ks + fh of its row, swizzled; tile rows are multiples of 32
+        // apart, so (row >> 2) & 3 only depends on fr
+        const __bf16 *Ah = lds + buf * BUF + (wm * WM + fr) * LDS_ROW;
+        const __bf16 *Al = Ah + BM * LDS_ROW;
+        const __bf16 *Bh = lds + buf * BUF + 2 * BM * LDS_ROW + (wn * WN + fr) * LDS_ROW;
+        const __bf16 *Bl = Bh + BN * LDS_ROW;
+        const int swz = (fr >> 2) & 3;
 #pragma unroll
         for (int ks = 0; ks < KB3 / 16; ++ks) {
+            const int ch = (((2 * ks + fh) ^ swz) & 3) << 3;
             bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                ah[i] = *reinterpret_cast<const bf16x8 *>(Ah + i * 32 * LDB + ks * 16);
-                al[i] = *reinterpret_cast<const bf16x8 *>(Al + i * 32 * LDB + ks * 16);
+                ah[i] = *reinterpret_cast<const bf16x8 *>(Ah + i * 32 * LDS_ROW + ch);
+                al[i] = *reinterpret_cast<const bf16x8 *>(Al + i * 32 * LDS_ROW + ch);
             }
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
-                bh[j] = *reinterpret_cast<const bf16x8 *>(Bh + j * 32 * LDB + ks * 16);
-                bl[j] = *reinterpret_cast<const bf16x8 *>(Bl + j * 32 * LDB + ks * 16);
+                bh[j] = *reinterpret_cast<const bf16x8 *>(Bh + j * 32 * LDS_ROW + ch);
+                bl[j] = *reinterpret_cast<const bf16x8 *>(Bl + j * 32 * LDS_ROW + ch);
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -228,6 +266,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
             }
         }
     }
+}
+
+// Data gradient (BT) launch: GEMM rows = a.out_rows, K = a.Cin (forward Cout), N = a.Cout (forward Cin) > 32.
+int launch_dgrad_b3(const ConvArgs &a, hipStream_t st) {
+    const int64_t big_blocks = cdiv(a.out_rows, 128) * cdiv(a.Cout, 128);
+    dim3 block(256);
+    if (big_blocks >= 384) k_conv_igemm_b3<128, 128, false, true><<<dim3(xcd_grid(cdiv(a.out_rows, 128), cdiv(a.Cout, 128))), block, 0, st>>>(a);
+    else k_conv_igemm_b3<64, 64, false, true><<<dim3(xcd_grid(cdiv(a.out_rows, 64), cdiv(a.Cout, 64))), block, 0, st>>>(a);
+    return RD_OK;
 }
 
 // Launch for Cout > 32 (narrower outputs stay on the exact-fp32 kernel: they are bandwidth-bound level-1 sparse convs).

@@ -199,7 +199,7 @@ def conv_fwd(x, weight_k, taps, bias, out_rows, Cout, ix, scale=None, shift=None
 
 
 def conv_dgrad(grad_out, weight_k, taps, in_rows, Cin, ix_bwd, nbr_keepalive=None):
-    """grad_out (out_rows, Cout), weight_k the FORWARD kernel layout (Cout, taps, Cin) -> grad_in (in_rows, Cin).  fp32 mode only."""
+    """grad_out (out_rows, Cout), weight_k the FORWARD kernel layout (Cout, taps, Cin) -> grad_in (in_rows, Cin)."""
     _chk(grad_out, f32, "dgrad grad_out", 2)
     _chk(weight_k, f32, "dgrad weight")
     out_rows, Cout = grad_out.shape
