@@ -174,7 +174,8 @@ int rd_bn_finalize(const float *stats, int64_t rows, int C, const float *gamma, 
 /* y = x*scale + shift (+ residual) ; act: 0 none, 1 relu, 2 gelu(erf). */
 int rd_affine_act(const float *x, int64_t rows, int C, const float *scale, const float *shift, const float *residual,
                   int act, float *y, void *stream);
-/* Backward of y = act(bn(x) + residual) in train mode.  Inputs: x (pre-BN), y (output, for the ReLU mask) or
+/* Backward of y = act(bn(x) + residual) in train mode.  Inputs: x (pre-BN), y (output, for the ReLU mask; may be NULL when
+ * there is no residual: the mask is then re-derived as x*scale + shift > 0, the forward's own expression), the
  * pre-activation recomputed for GELU, grad_y.  Outputs grad_x, grad_gamma, grad_beta, grad_residual (= masked grad_y,
  * may be NULL).  grad_gamma / grad_beta are ACCUMULATED with fp32 atomics by the reduction pass and then read by the apply
  * pass: the caller zero-fills them. */

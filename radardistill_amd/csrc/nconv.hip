@@ -13,6 +13,7 @@
 // lanes of a pixel read one contiguous 256-byte LDS row and weights / weight-gradient accumulators ([n][9 taps][4 channels])
 // live in registers for the whole band.  The 10x10x64 input halo of a tile is staged through LDS once (1.56x re-read from L2
 // instead of 9x).  HBM-bound: y is 352 MB at B = 8, 64x64 map, 42 branches.
+#include <algorithm>
 #include "common.hpp"
 
 using namespace rd;
@@ -47,15 +48,30 @@ __device__ __forceinline__ float reduce16(float v) {
     return v;
 }
 
-// stage the 10x10 halo (all 64 channels of branch `cin0`) of tile (y0, x0) of image b
-__device__ __forceinline__ void load_halo(const NconvArgs &a, int b, int y0, int x0, int cin0, float *lds) {
-    for (int i = threadIdx.x; i < NC_HALO * NC_HALO * (NC_CB / 4); i += 256) {
-        const int hp = i >> 4, q = i & 15;
-        const int gy = y0 - 1 + hp / NC_HALO, gx = x0 - 1 + hp % NC_HALO;
+// The 10x10x64 halo of a tile is 1600 float4: 7 per thread (the last pass covers 64 of the 256 threads).  It is fetched into
+// registers one tile AHEAD (the loads fly under the current tile's arithmetic) and written to LDS after the barrier.
+constexpr int NC_HP = (NC_HALO * NC_HALO * (NC_CB / 4) + 255) / 256;   // 7
+
+__device__ __forceinline__ void halo_fetch(const NconvArgs &a, int b, int y0, int x0, int cin0, f32x4 (&pre)[NC_HP]) {
+#pragma unroll
+    for (int p = 0; p < NC_HP; ++p) {
+        const int i = threadIdx.x + 256 * p;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-            v = *reinterpret_cast<const f32x4 *>(a.y + ((int64_t)(b * a.H + gy) * a.W + gx) * a.ldy + cin0 + 4 * q);
-        *reinterpret_cast<f32x4 *>(lds + hp * NC_LDW + 4 * q) = v;
+        if (i < NC_HALO * NC_HALO * (NC_CB / 4)) {
+            const int hp = i >> 4, q = i & 15;
+            const int gy = y0 - 1 + hp / NC_HALO, gx = x0 - 1 + hp % NC_HALO;
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                v = *reinterpret_cast<const f32x4 *>(a.y + ((int64_t)(b * a.H + gy) * a.W + gx) * a.ldy + cin0 + 4 * q);
+        }
+        pre[p] = v;
+    }
+}
+
+__device__ __forceinline__ void halo_store(const f32x4 (&pre)[NC_HP], float *lds) {
+#pragma unroll
+    for (int p = 0; p < NC_HP; ++p) {
+        const int i = threadIdx.x + 256 * p;
+        if (i < NC_HALO * NC_HALO * (NC_CB / 4)) *reinterpret_cast<f32x4 *>(lds + (i >> 4) * NC_LDW + 4 * (i & 15)) = pre[p];
     }
 }
 
@@ -80,9 +96,12 @@ __device__ __forceinline__ void nconv_fwd_body(const NconvArgs &a, float *lds) {
     float bias[N];
 #pragma unroll
     for (int n = 0; n < N; ++n) bias[n] = a.bias ? a.bias[col0 + n] : 0.f;
+    f32x4 pre[NC_HP];
+    halo_fetch(a, b, y0, 0, cin0, pre);
     for (int x0 = 0; x0 < a.W; x0 += NC_T) {
-        load_halo(a, b, y0, x0, cin0, lds);
+        halo_store(pre, lds);
         __syncthreads();
+        if (x0 + NC_T < a.W) halo_fetch(a, b, y0, x0 + NC_T, cin0, pre);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int p = pg + 16 * i, py = p >> 3, px = p & 7;
@@ -109,14 +128,16 @@ __device__ __forceinline__ void nconv_fwd_body(const NconvArgs &a, float *lds) {
     }
 }
 
+// NMAX = widest branch of the launch (3 on nuScenes): the <4> bodies are only compiled into the NMAX = 4 kernels, whose weight /
+// accumulator arrays would otherwise set the register count (and halve the resident waves) for every launch.
+template <int NMAX>
 __global__ __launch_bounds__(256) void k_nconv_fwd(const NconvArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[NC_HALO * NC_HALO * NC_LDW];
-    switch (a.n_out[blockIdx.y]) {  // block-uniform
-        case 1: nconv_fwd_body<1>(a, lds); break;
-        case 2: nconv_fwd_body<2>(a, lds); break;
-        case 3: nconv_fwd_body<3>(a, lds); break;
-        default: nconv_fwd_body<4>(a, lds); break;
-    }
+    const int n = a.n_out[blockIdx.y];  // block-uniform
+    if (n == 1) nconv_fwd_body<1>(a, lds);
+    else if (n == 2) nconv_fwd_body<2>(a, lds);
+    else if (n == 3 || NMAX == 3) nconv_fwd_body<3>(a, lds);
+    else nconv_fwd_body<NMAX>(a, lds);
 }
 
 // grad_y[q][cin0 + c] = sum_t sum_n go[q - d_t][col0 + n] * w[col0 + n][c][t],  d_t = (t/3 - 1, t%3 - 1)
@@ -160,14 +181,14 @@ __device__ __forceinline__ void nconv_dgrad_body(const NconvArgs &a, float *lds)
     }
 }
 
+template <int NMAX>
 __global__ __launch_bounds__(256) void k_nconv_dgrad(const NconvArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[NC_HALO * NC_HALO * NC_MAXN];
-    switch (a.n_out[blockIdx.y]) {
-        case 1: nconv_dgrad_body<1>(a, lds); break;
-        case 2: nconv_dgrad_body<2>(a, lds); break;
-        case 3: nconv_dgrad_body<3>(a, lds); break;
-        default: nconv_dgrad_body<4>(a, lds); break;
-    }
+    const int n = a.n_out[blockIdx.y];
+    if (n == 1) nconv_dgrad_body<1>(a, lds);
+    else if (n == 2) nconv_dgrad_body<2>(a, lds);
+    else if (n == 3 || NMAX == 3) nconv_dgrad_body<3>(a, lds);
+    else nconv_dgrad_body<NMAX>(a, lds);
 }
 
 // grad_w[col0 + n][c][t] += sum_p go[p][col0 + n] * y[p + d_t][cin0 + c]   (fp32 atomics combine the bands)
@@ -184,14 +205,17 @@ __device__ __forceinline__ void nconv_wgrad_body(const NconvArgs &a, float *lds,
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[n][t][j] = 0.f;
+    f32x4 pre[NC_HP];
+    halo_fetch(a, b, y0, 0, cin0, pre);
     for (int x0 = 0; x0 < a.W; x0 += NC_T) {
-        load_halo(a, b, y0, x0, cin0, lds);
+        halo_store(pre, lds);
         for (int i = threadIdx.x; i < NC_T * NC_T * N; i += 256) {
             const int p = i / N, n = i % N;
             const int gy = y0 + (p >> 3), gx = x0 + (p & 7);
             g_l[p * NC_MAXN + n] = (gy < a.H && gx < a.W) ? a.go[((int64_t)(b * a.H + gy) * a.W + gx) * a.NO + col0 + n] : 0.f;
         }
         __syncthreads();
+        if (x0 + NC_T < a.W) halo_fetch(a, b, y0, x0 + NC_T, cin0, pre);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int p = pg + 16 * i, py = p >> 3, px = p & 7;
@@ -225,16 +249,16 @@ __device__ __forceinline__ void nconv_wgrad_body(const NconvArgs &a, float *lds,
     }
 }
 
+template <int NMAX>
 __global__ __launch_bounds__(256) void k_nconv_wgrad(const NconvArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[NC_HALO * NC_HALO * NC_LDW];
     __shared__ float g_l[NC_T * NC_T * NC_MAXN];
     __shared__ float red[NC_MAXN * NC_CB * 9];
-    switch (a.n_out[blockIdx.y]) {
-        case 1: nconv_wgrad_body<1>(a, lds, g_l, red); break;
-        case 2: nconv_wgrad_body<2>(a, lds, g_l, red); break;
-        case 3: nconv_wgrad_body<3>(a, lds, g_l, red); break;
-        default: nconv_wgrad_body<4>(a, lds, g_l, red); break;
-    }
+    const int n = a.n_out[blockIdx.y];
+    if (n == 1) nconv_wgrad_body<1>(a, lds, g_l, red);
+    else if (n == 2) nconv_wgrad_body<2>(a, lds, g_l, red);
+    else if (n == 3 || NMAX == 3) nconv_wgrad_body<3>(a, lds, g_l, red);
+    else nconv_wgrad_body<NMAX>(a, lds, g_l, red);
 }
 
 static int fill_args(NconvArgs &a, const char *who, int B, int H, int W, int ldy, int NO, int NB, const int32_t *cin_off, const int32_t *col_off,
@@ -255,6 +279,12 @@ static int fill_args(NconvArgs &a, const char *who, int B, int H, int W, int ldy
     return RD_OK;
 }
 
+static int max_width(const NconvArgs &a) {
+    int m = 1;
+    for (int b = 0; b < a.NB; ++b) m = std::max(m, a.n_out[b]);
+    return m;
+}
+
 extern "C" int rd_nconv_fwd(const float *y, int ldy, const float *weight, const float *bias, int B, int H, int W, int NO, int NB,
                             const int32_t *cin_off, const int32_t *col_off, const int32_t *n_out, float *out, void *stream) {
     NconvArgs a{};
@@ -262,7 +292,8 @@ extern "C" int rd_nconv_fwd(const float *y, int ldy, const float *weight, const 
     if (rc) return rc;
     a.y = y; a.w = weight; a.bias = bias; a.out = out;
     dim3 grid((unsigned)(B * cdiv(H, NC_T)), (unsigned)NB);
-    k_nconv_fwd<<<grid, 256, 0, S(stream)>>>(a);
+    if (max_width(a) <= 3) k_nconv_fwd<3><<<grid, 256, 0, S(stream)>>>(a);
+    else k_nconv_fwd<4><<<grid, 256, 0, S(stream)>>>(a);
     return check_launch("rd_nconv_fwd");
 }
 
@@ -273,7 +304,8 @@ extern "C" int rd_nconv_dgrad(const float *grad_out, const float *weight, int B,
     if (rc) return rc;
     a.go = grad_out; a.w = weight; a.out = grad_y;
     dim3 grid((unsigned)(B * cdiv(H, NC_T)), (unsigned)NB);
-    k_nconv_dgrad<<<grid, 256, 0, S(stream)>>>(a);
+    if (max_width(a) <= 3) k_nconv_dgrad<3><<<grid, 256, 0, S(stream)>>>(a);
+    else k_nconv_dgrad<4><<<grid, 256, 0, S(stream)>>>(a);
     return check_launch("rd_nconv_dgrad");
 }
 
@@ -284,6 +316,7 @@ extern "C" int rd_nconv_wgrad(const float *y, int ldy, const float *grad_out, in
     if (rc) return rc;
     a.y = y; a.go = grad_out; a.out = grad_w;
     dim3 grid((unsigned)(B * cdiv(H, NC_T)), (unsigned)NB);
-    k_nconv_wgrad<<<grid, 256, 0, S(stream)>>>(a);
+    if (max_width(a) <= 3) k_nconv_wgrad<3><<<grid, 256, 0, S(stream)>>>(a);
+    else k_nconv_wgrad<4><<<grid, 256, 0, S(stream)>>>(a);
     return check_launch("rd_nconv_wgrad");
 }

@@ -149,31 +149,27 @@ extern "C" int rd_affine_act(const float *x, int64_t rows, int C, const float *s
     return check_launch("rd_affine_act");
 }
 
-// Train-mode BatchNorm forward in ONE launch: every thread derives scale/shift of its 4 channels from the batch sums (a few
-// double operations, channels stay fixed over the grid-stride loop when the stride is a multiple of C/4), block 0 also writes
+// Train-mode BatchNorm forward in ONE launch: every block derives scale/shift of all C channels from the batch sums into LDS
+// (C / 256 channels per thread, a few double operations each), then streams its share of the rows; block 0 also writes
 // mean / rstd / scale / shift for the backward pass and updates the running statistics.
-__global__ void k_bn_train_fwd(const float *__restrict__ x, int64_t n4, int C, const float *__restrict__ stats, float n,
-                               const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float momentum,
-                               float *running_mean, float *running_var, const float *__restrict__ residual, int act, float *__restrict__ y,
-                               float *mean_out, float *rstd_out, float *scale_out, float *shift_out) {
-    auto channel = [&](int c, float &sc, float &sh, float &mean_f, float &rstd_f, double &var_d) {
+__global__ __launch_bounds__(256) void k_bn_train_fwd(const float *__restrict__ x, int64_t n4, int C, const float *__restrict__ stats, float n,
+                                                      const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float momentum,
+                                                      float *running_mean, float *running_var, const float *__restrict__ residual, int act,
+                                                      float *__restrict__ y, float *mean_out, float *rstd_out, float *scale_out, float *shift_out) {
+    extern __shared__ float sc_sh[];  // [C] scale, [C] shift
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const double mean = (double)stats[c] / n;
         double var = (double)stats[C + c] / n - mean * mean;
         if (var < 0.0) var = 0.0;
-        rstd_f = (float)(1.0 / sqrt(var + (double)eps));
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
         const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-        sc = g * rstd_f;
-        mean_f = (float)mean;
-        sh = b - mean_f * sc;
-        var_d = var;
-    };
-    if (blockIdx.x == 0) {
-        for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            float sc, sh, m, r;
-            double var;
-            channel(c, sc, sh, m, r, var);
+        const float sc = g * rstd, m = (float)mean;
+        const float sh = b - m * sc;
+        sc_sh[c] = sc;
+        sc_sh[C + c] = sh;
+        if (blockIdx.x == 0) {
             if (mean_out) mean_out[c] = m;
-            if (rstd_out) rstd_out[c] = r;
+            if (rstd_out) rstd_out[c] = rstd;
             if (scale_out) scale_out[c] = sc;
             if (shift_out) shift_out[c] = sh;
             if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
@@ -183,24 +179,15 @@ __global__ void k_bn_train_fwd(const float *__restrict__ x, int64_t n4, int C, c
             }
         }
     }
+    __syncthreads();
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const bool fixed = (stride * 4) % C == 0;
-    f32x4 sc4, sh4;
-    int c_prev = -1;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         const int c = (int)((i * 4) % C);
-        if (!fixed || c_prev < 0) {
+        const f32x4 xv = reinterpret_cast<const f32x4 *>(x)[i];
+        const f32x4 sc4 = *reinterpret_cast<const f32x4 *>(sc_sh + c), sh4 = *reinterpret_cast<const f32x4 *>(sc_sh + C + c);
+        f32x4 v;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float m, r, a_, b_;
-                double var;
-                channel(c + k, a_, b_, m, r, var);
-                sc4[k] = a_;
-                sh4[k] = b_;
-            }
-            c_prev = c;
-        }
-        f32x4 v = reinterpret_cast<const f32x4 *>(x)[i] * sc4 + sh4;
+        for (int k = 0; k < 4; ++k) v[k] = fmaf(xv[k], sc4[k], sh4[k]);   // the backward pass re-derives the ReLU mask with this exact expression
         if (residual) v += reinterpret_cast<const f32x4 *>(residual)[i];
         if (act == 1) {
             for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
@@ -215,11 +202,12 @@ extern "C" int rd_bn_train_fwd(const float *x, int64_t rows, int C, const float 
                                float momentum, float *running_mean, float *running_var, const float *residual, int act, float *y,
                                float *mean, float *rstd, float *scale, float *shift, void *stream) {
     RD_REQUIRE(rows > 0, "rd_bn_train_fwd: BatchNorm over zero rows");
-    RD_REQUIRE(C % 4 == 0 && act >= 0 && act <= 2, "rd_bn_train_fwd: C=%d must be a multiple of 4, act in 0..2", C);
+    RD_REQUIRE(C % 4 == 0 && C <= 8192 && act >= 0 && act <= 2, "rd_bn_train_fwd: C=%d must be a multiple of 4 (<= 8192), act in 0..2", C);
     const int64_t n4 = rows * C / 4;
-    const int blocks = (int)std::min<int64_t>(cdiv(n4, 256), 4096);
-    k_bn_train_fwd<<<blocks, 256, 0, S(stream)>>>(x, n4, C, stats, (float)rows, gamma, beta, eps, momentum, running_mean, running_var, residual,
-                                                  act, y, mean, rstd, scale, shift);
+    // >= 8 float4 per thread, so the per-block scale/shift table (C/256 channels per thread) is amortised
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n4, 256 * 8), 2048));
+    k_bn_train_fwd<<<blocks, 256, (size_t)2 * C * 4, S(stream)>>>(x, n4, C, stats, (float)rows, gamma, beta, eps, momentum, running_mean,
+                                                                   running_var, residual, act, y, mean, rstd, scale, shift);
     return check_launch("rd_bn_train_fwd");
 }
 
@@ -234,8 +222,12 @@ struct BnBwdF {
         f32x4 g = *reinterpret_cast<const f32x4 *>(gy + r * C + c);
         f32x4 xv = *reinterpret_cast<const f32x4 *>(x + r * C + c);
         if (act == 1) {
-            f32x4 yv = *reinterpret_cast<const f32x4 *>(y + r * C + c);
-            for (int k = 0; k < 4; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+            if (y) {
+                f32x4 yv = *reinterpret_cast<const f32x4 *>(y + r * C + c);
+                for (int k = 0; k < 4; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+            } else {  // no residual: the mask is (x*scale + shift > 0), the forward's own expression -- one tensor less to read
+                for (int k = 0; k < 4; ++k) g[k] = fmaf(xv[k], scale[c + k], shift[c + k]) > 0.f ? g[k] : 0.f;
+            }
         } else if (act == 2) {
             for (int k = 0; k < 4; ++k) g[k] *= gelu_grad(fmaf(xv[k], scale[c + k], shift[c + k]));
         }
@@ -255,8 +247,12 @@ __global__ void k_bn_bwd_apply(const float *__restrict__ x, const float *__restr
         f32x4 g = reinterpret_cast<const f32x4 *>(gy)[i];
         f32x4 xv = reinterpret_cast<const f32x4 *>(x)[i];
         if (act == 1) {
-            f32x4 yv = reinterpret_cast<const f32x4 *>(y)[i];
-            for (int k = 0; k < 4; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+            if (y) {
+                f32x4 yv = reinterpret_cast<const f32x4 *>(y)[i];
+                for (int k = 0; k < 4; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+            } else {
+                for (int k = 0; k < 4; ++k) g[k] = fmaf(xv[k], scale[c + k], shift[c + k]) > 0.f ? g[k] : 0.f;
+            }
         } else if (act == 2) {
             for (int k = 0; k < 4; ++k) g[k] *= gelu_grad(fmaf(xv[k], scale[c + k], shift[c + k]));
         }
@@ -277,6 +273,7 @@ extern "C" int rd_bn_bwd(const float *x, const float *y, const float *grad_y, in
     RD_REQUIRE(rows > 0, "rd_bn_bwd: zero rows");
     RD_REQUIRE(act >= 0 && act <= 2, "rd_bn_bwd: bad act");
     RD_REQUIRE(!(act == 2 && has_residual), "rd_bn_bwd: gelu with residual is not supported");
+    RD_REQUIRE(!(act == 1 && has_residual && y == nullptr), "rd_bn_bwd: y is required for ReLU with a residual (the mask depends on the residual)");
     RD_REQUIRE(grad_gamma && grad_beta, "rd_bn_bwd: grad_gamma / grad_beta are required (zero-filled by the caller; the apply kernel reads them)");
     hipStream_t st = S(stream);
     int rc = colreduce(rows, C, BnBwdF{x, y, grad_y, mean, rstd, scale, shift, C, act}, grad_beta, grad_gamma, st, "rd_bn_bwd");

@@ -342,6 +342,8 @@ def bn_bwd(x, y, grad_y, gamma, mean, rstd, scale, shift, act, has_residual):
     from . import autograd as _A
     g2 = _A.zeros_accum(2 * C, x.device)            # [grad_gamma | grad_beta], accumulated by the reduction pass
     gg, gb = g2[:C], g2[C:]
+    if act == 1 and not has_residual:
+        y = None                                     # ReLU mask re-derived from x*scale + shift: one tensor less to stream
     check(native.lib().rd_bn_bwd(_p(x), _p(y), _p(grad_y), rows, C, _p(gamma), _p(mean), _p(rstd), _p(scale), _p(shift), act,
                                  int(has_residual), _p(gx), _p(gres), _p(gg), _p(gb), _stream()), "rd_bn_bwd")
     return gx, gres, gg, gb
