@@ -35,9 +35,10 @@ __global__ __launch_bounds__(256) void k_colreduce(int64_t rows, int C, F f, flo
     const int g = tid / tpr, c4 = (tid % tpr) * 4;
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     if (g < groups) {
+        const typename F::Ctx ctx = f.prepare(col0 + c4);
         for (int64_t r = (int64_t)blockIdx.x * groups + g; r < rows; r += (int64_t)gridDim.x * groups) {
             f32x4 a, b;
-            f(r, col0 + c4, a, b);
+            f(ctx, r, col0 + c4, a, b);
             s1 += a;
             s2 += b;
         }
@@ -65,10 +66,13 @@ static int colreduce(int64_t rows, int C, F f, float *out1, float *out2, hipStre
     return check_launch(who);
 }
 
+// Functors: prepare(c) loads whatever depends only on the thread's 4 channels (fixed over its row loop) into registers.
 struct StatsF {
     const float *x;
     int C;
-    __device__ void operator()(int64_t r, int c, f32x4 &a, f32x4 &b) const {
+    struct Ctx {};
+    __device__ Ctx prepare(int) const { return Ctx{}; }
+    __device__ void operator()(const Ctx &, int64_t r, int c, f32x4 &a, f32x4 &b) const {
         a = *reinterpret_cast<const f32x4 *>(x + r * C + c);
         b = a * a;
     }
@@ -82,7 +86,9 @@ extern "C" int rd_bn_stats(const float *x, int64_t rows, int C, float *stats, vo
 struct ColsumF {
     const float *x;
     int C;
-    __device__ void operator()(int64_t r, int c, f32x4 &a, f32x4 &b) const {
+    struct Ctx {};
+    __device__ Ctx prepare(int) const { return Ctx{}; }
+    __device__ void operator()(const Ctx &, int64_t r, int c, f32x4 &a, f32x4 &b) const {
         a = *reinterpret_cast<const f32x4 *>(x + r * C + c);
         b = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -218,7 +224,18 @@ extern "C" int rd_bn_train_fwd(const float *x, int64_t rows, int C, const float 
 struct BnBwdF {
     const float *x, *y, *gy, *mean, *rstd, *scale, *shift;
     int C, act;
-    __device__ void operator()(int64_t r, int c, f32x4 &a, f32x4 &b) const {
+    struct Ctx {
+        f32x4 mean, rstd, sc, sh;
+    };
+    __device__ Ctx prepare(int c) const {
+        Ctx k;
+        k.mean = *reinterpret_cast<const f32x4 *>(mean + c);
+        k.rstd = *reinterpret_cast<const f32x4 *>(rstd + c);
+        k.sc = *reinterpret_cast<const f32x4 *>(scale + c);
+        k.sh = *reinterpret_cast<const f32x4 *>(shift + c);
+        return k;
+    }
+    __device__ void operator()(const Ctx &p, int64_t r, int c, f32x4 &a, f32x4 &b) const {
         f32x4 g = *reinterpret_cast<const f32x4 *>(gy + r * C + c);
         f32x4 xv = *reinterpret_cast<const f32x4 *>(x + r * C + c);
         if (act == 1) {
@@ -226,43 +243,52 @@ struct BnBwdF {
                 f32x4 yv = *reinterpret_cast<const f32x4 *>(y + r * C + c);
                 for (int k = 0; k < 4; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
             } else {  // no residual: the mask is (x*scale + shift > 0), the forward's own expression -- one tensor less to read
-                for (int k = 0; k < 4; ++k) g[k] = fmaf(xv[k], scale[c + k], shift[c + k]) > 0.f ? g[k] : 0.f;
+                for (int k = 0; k < 4; ++k) g[k] = fmaf(xv[k], p.sc[k], p.sh[k]) > 0.f ? g[k] : 0.f;
             }
         } else if (act == 2) {
-            for (int k = 0; k < 4; ++k) g[k] *= gelu_grad(fmaf(xv[k], scale[c + k], shift[c + k]));
+            for (int k = 0; k < 4; ++k) g[k] *= gelu_grad(fmaf(xv[k], p.sc[k], p.sh[k]));
         }
-        f32x4 xh;
-        for (int k = 0; k < 4; ++k) xh[k] = (xv[k] - mean[c + k]) * rstd[c + k];
         a = g;
-        b = g * xh;
+        b = g * ((xv - p.mean) * p.rstd);
     }
 };
 
-__global__ void k_bn_bwd_apply(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ gy, int64_t n4, int C,
-                               const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ rstd,
-                               const float *__restrict__ scale, const float *__restrict__ shift, int act, const float *__restrict__ sum_g,
-                               const float *__restrict__ sum_gx, float inv_n, float *__restrict__ gx, float *__restrict__ gres) {
+// dx = gamma*rstd*(g' - sum_g/n - xhat*sum_gx/n) = A*g' + B*x + D per channel; the five per-channel coefficients (A, B, D and the
+// forward's scale / shift for the activation mask) are built once per block in LDS.
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ gy,
+                                                      int64_t n4, int C, const float *__restrict__ gamma, const float *__restrict__ mean,
+                                                      const float *__restrict__ rstd, const float *__restrict__ scale,
+                                                      const float *__restrict__ shift, int act, const float *__restrict__ sum_g,
+                                                      const float *__restrict__ sum_gx, float inv_n, float *__restrict__ gx,
+                                                      float *__restrict__ gres) {
+    extern __shared__ float tab[];  // [5][C]: A, B, D, scale, shift
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float r = rstd[c], A = (gamma ? gamma[c] : 1.f) * r;
+        const float Bc = -A * r * (sum_gx[c] * inv_n);
+        tab[c] = A;
+        tab[C + c] = Bc;
+        tab[2 * C + c] = -A * (sum_g[c] * inv_n) - Bc * mean[c];
+        tab[3 * C + c] = scale[c];
+        tab[4 * C + c] = shift[c];
+    }
+    __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        int c = (int)((i * 4) % C);
+        const int c = (int)((i * 4) % C);
         f32x4 g = reinterpret_cast<const f32x4 *>(gy)[i];
-        f32x4 xv = reinterpret_cast<const f32x4 *>(x)[i];
+        const f32x4 xv = reinterpret_cast<const f32x4 *>(x)[i];
         if (act == 1) {
             if (y) {
-                f32x4 yv = reinterpret_cast<const f32x4 *>(y)[i];
+                const f32x4 yv = reinterpret_cast<const f32x4 *>(y)[i];
                 for (int k = 0; k < 4; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
             } else {
-                for (int k = 0; k < 4; ++k) g[k] = fmaf(xv[k], scale[c + k], shift[c + k]) > 0.f ? g[k] : 0.f;
+                for (int k = 0; k < 4; ++k) g[k] = fmaf(xv[k], tab[3 * C + c + k], tab[4 * C + c + k]) > 0.f ? g[k] : 0.f;
             }
         } else if (act == 2) {
-            for (int k = 0; k < 4; ++k) g[k] *= gelu_grad(fmaf(xv[k], scale[c + k], shift[c + k]));
+            for (int k = 0; k < 4; ++k) g[k] *= gelu_grad(fmaf(xv[k], tab[3 * C + c + k], tab[4 * C + c + k]));
         }
         if (gres) reinterpret_cast<f32x4 *>(gres)[i] = g;
         f32x4 o;
-        for (int k = 0; k < 4; ++k) {
-            float xh = (xv[k] - mean[c + k]) * rstd[c + k];
-            float ga = gamma ? gamma[c + k] : 1.f;
-            o[k] = ga * rstd[c + k] * (g[k] - sum_g[c + k] * inv_n - xh * sum_gx[c + k] * inv_n);
-        }
+        for (int k = 0; k < 4; ++k) o[k] = fmaf(tab[c + k], g[k], fmaf(tab[C + c + k], xv[k], tab[2 * C + c + k]));
         reinterpret_cast<f32x4 *>(gx)[i] = o;
     }
 }
@@ -279,8 +305,9 @@ extern "C" int rd_bn_bwd(const float *x, const float *y, const float *grad_y, in
     int rc = colreduce(rows, C, BnBwdF{x, y, grad_y, mean, rstd, scale, shift, C, act}, grad_beta, grad_gamma, st, "rd_bn_bwd");
     if (rc) return rc;
     int64_t n4 = rows * C / 4;
-    int blocks = (int)std::min<int64_t>(cdiv(n4, 256), 4096);
-    k_bn_bwd_apply<<<blocks, 256, 0, st>>>(x, y, grad_y, n4, C, gamma, mean, rstd, scale, shift, act, grad_beta, grad_gamma, 1.0f / (float)rows,
+    RD_REQUIRE(C <= 8192, "rd_bn_bwd: C=%d > 8192", C);
+    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n4, 256 * 8), 2048));   // >= 8 float4 per thread: the LDS table is amortised
+    k_bn_bwd_apply<<<blocks, 256, (size_t)5 * C * 4, st>>>(x, y, grad_y, n4, C, gamma, mean, rstd, scale, shift, act, grad_beta, grad_gamma, 1.0f / (float)rows,
                                            grad_x, has_residual ? grad_res : nullptr);
     return check_launch("rd_bn_bwd");
 }
