@@ -249,7 +249,7 @@ static int g_conv_math = 0;
 int launch_conv_b3(const ConvArgs &a, int mode, hipStream_t st);
 int launch_dgrad_b3(const ConvArgs &a, hipStream_t st);
 int launch_wgrad_b3(const float *in, int in_rows, int Cin, const float *go, int out_rows, int Cout, int taps, const rd_conv_index *idx, float *gw,
-                    int rows_per_block, int64_t chunks, int tiles, hipStream_t st);
+                    int rows_per_block, int64_t chunks, int tiles, int cin_tile, hipStream_t st);
 extern "C" int rd_set_conv_math(int mode) {
     RD_REQUIRE(mode == 0 || mode == 1, "rd_set_conv_math: mode must be 0 (f32) or 1 (bf16x3)");
     g_conv_math = mode;
@@ -549,31 +549,35 @@ extern "C" int rd_conv_wgrad(const float *in, int in_rows, int Cin, const float 
     int rc = validate_index(idx, taps, in_rows, out_rows, "rd_conv_wgrad");
     if (rc) return rc;
     if (out_rows == 0) return RD_OK;
-    // 128-wide Cin tiles when that still leaves >= 32 (tap, tile) pairs to spread over the chip (3x3 convs); 1x1 convs keep 64
-    const bool wide = Cin >= 128 && Cout >= 64 && (int64_t)taps * cdiv(Cout, WG_BM) * cdiv(Cin, 128) >= 32;
+    // bf16x3 mode: every shape with Cout >= 64 and Cin >= 64 runs the split-bf16 kernel (Cin tile 128, or 64 when Cin == 64).
+    // Exact fp32: 128-wide Cin tiles when that still leaves >= 32 (tap, tile) pairs to spread over the chip (3x3 convs); 1x1 keep 64.
+    const bool b3 = g_conv_math == 1 && Cout >= 64 && Cin >= 64;
+    const bool wide = b3 ? Cin >= 128 : (Cin >= 128 && Cout >= 64 && (int64_t)taps * cdiv(Cout, WG_BM) * cdiv(Cin, 128) >= 32);
     const int bn = wide ? 128 : 64;
     const int n_mt = (int)cdiv(Cout, WG_BM), n_nt = (int)cdiv(Cin, bn);
     const int tiles = taps * n_mt * n_nt;
     // Row chunks.  512 workgroups are resident at once (two per CU); a launch runs in ceil(chunks*tiles/512) rounds of
     // rows/chunks rows each, and every block ends with an atomic pass over its tile (memory-side atomics, ~1.3 TB/s chip-wide:
     // ~50k cycles per round for 128x128 tiles).  Pick the chunk count with the smallest modelled time; >= 256 rows per block.
+    // (bf16x3 spends about a third of the fp32 cycles per row.)
     int64_t chunks = 1;
-    if (taps == 1) {  // 1x1 convs: little work per (tile, chunk), latency bound -> more, smaller blocks (measured 75 us vs 102 us)
+    if (taps == 1 && !b3) {  // 1x1 convs: little work per (tile, chunk), latency bound -> more, smaller blocks (measured 75 us vs 102 us)
         chunks = std::max<int64_t>(1, std::min<int64_t>(cdiv(out_rows, 256), cdiv(2048, tiles)));
     } else {
         const int64_t max_chunks = std::max<int64_t>(1, std::min<int64_t>(cdiv(out_rows, 256), 128));
+        const double row_cycles = (b3 ? 0.7 : 2.0) * bn;
         double best = 1e30;
         for (int64_t c = 1; c <= max_chunks; ++c) {
             const double rounds = (double)cdiv(c * tiles, 512);
-            const double cost = rounds * ((double)cdiv(out_rows, c) * 2.0 * bn + 50000.0 * bn / 128.0);
+            const double cost = rounds * ((double)cdiv(out_rows, c) * row_cycles + 50000.0 * bn / 128.0);
             if (cost < best) { best = cost; chunks = c; }
         }
     }
     int rows_per_block = (int)(cdiv(cdiv(out_rows, chunks), WG_KB) * WG_KB);
     chunks = cdiv(out_rows, rows_per_block);
     hipStream_t st = S(stream);
-    if (g_conv_math == 1 && wide) {   // bf16x3: the 128x128-tile split-bf16 kernel (conv_b3.hip); narrow shapes stay exact fp32
-        launch_wgrad_b3(in, in_rows, Cin, grad_out, out_rows, Cout, taps, idx, grad_wk, rows_per_block, chunks, tiles, st);
+    if (b3) {
+        launch_wgrad_b3(in, in_rows, Cin, grad_out, out_rows, Cout, taps, idx, grad_wk, rows_per_block, chunks, tiles, bn, st);
         return check_launch("rd_conv_wgrad(bf16x3)");
     }
     WgradArgs a{in, in_rows, Cin, grad_out, out_rows, Cout, taps, *idx, grad_wk, rows_per_block};

@@ -309,29 +309,31 @@ struct WgradArgsB3 {
     int rows_per_block;
 };
 
-template <bool DEFORM>
+// TN = Cin tile (128, or 64 for Cin <= 64 layers such as the batched CenterHead first conv); the Cout tile is always 128.
+template <bool DEFORM, int TN>
 __global__ __launch_bounds__(256, 2) void k_conv_wgrad_b3(const WgradArgsB3 a) {
-    constexpr int T = 128;                       // tile edge (Cout and Cin)
-    __shared__ __attribute__((aligned(16))) __bf16 lds[4 * T * LDB];   // [G hi][G lo][X hi][X lo], each [128 channels][40]
+    constexpr int T = 128;                       // Cout tile
+    constexpr int NJ = TN / 64;                  // 32-wide MFMA column tiles per wave (wave tile 64 couts x TN/2 cins)
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * (T + TN) * LDB];   // [G hi][G lo][X hi][X lo], rows of 40 bf16
     __shared__ int s_any;
-    __bf16 *Gh = lds, *Gl = Gh + T * LDB, *Xh = Gl + T * LDB, *Xl = Xh + T * LDB;
+    __bf16 *Gh = lds, *Gl = Gh + T * LDB, *Xh = Gl + T * LDB, *Xl = Xh + TN * LDB;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int tile = blockIdx.y;
-    const int n_nt = (a.Cin + T - 1) / T, n_mt = (a.Cout + T - 1) / T;
+    const int n_nt = (a.Cin + TN - 1) / TN, n_mt = (a.Cout + T - 1) / T;
     const int t = tile / (n_mt * n_nt);
     const int mt = (tile / n_nt) % n_mt, nt = tile % n_nt;
-    const int co0 = mt * T, ci0 = nt * T;
+    const int co0 = mt * T, ci0 = nt * TN;
     const int r_begin = blockIdx.x * a.rows_per_block;
     const int r_end = min(a.out_rows, r_begin + a.rows_per_block);
     const int n_steps = (r_end - r_begin + KB3 - 1) / KB3;
     const int g = tid & 7, q = tid >> 3;         // rows 4g..4g+3 of the step, channels 4q..4q+3 of the tile
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_b3(const WgradArgsB3 a) {
                     const int4 c4 = *reinterpret_cast<const int4 *>(a.ix.samp_idx + o);
                     if (max(max(c4.x, c4.y), max(c4.z, c4.w)) >= 0) {
                         any_next = 1;
-                        if (ci0 + 4 * q < a.Cin) {
+                        if (4 * q < TN && ci0 + 4 * q < a.Cin) {
                             const f32x4 w = *reinterpret_cast<const f32x4 *>(a.ix.samp_w + o);
                             const float *base = a.in + ci0 + 4 * q;
                             if (c4.x >= 0) v += w[0] * *reinterpret_cast<const f32x4 *>(base + (int64_t)c4.x * a.Cin);
@@ -397,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_b3(const WgradArgsB3 a) {
                 if (dense) advance(b, y, x, 1);
                 if (src >= 0) {
                     any_next = 1;
-                    if (ci0 + 4 * q < a.Cin) v = *reinterpret_cast<const f32x4 *>(a.in + (int64_t)src * a.Cin + ci0 + 4 * q);
+                    if (4 * q < TN && ci0 + 4 * q < a.Cin) v = *reinterpret_cast<const f32x4 *>(a.in + (int64_t)src * a.Cin + ci0 + 4 * q);
                 }
             }
             rx[e] = v;
@@ -440,28 +442,31 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_b3(const WgradArgsB3 a) {
     for (int s = 0; s < n_steps; ++s) {
         __syncthreads();                          // previous step's fragment reads are done
         store_block(rg, Gh, Gl);
-        store_block(rx, Xh, Xl);
+        if (4 * q < TN) store_block(rx, Xh, Xl);
         if (any_next) s_any = s + 1;              // tag = step index + 1: no reset pass needed
         __syncthreads();
         const bool any = s_any == s + 1;
         if (s + 1 < n_steps) load_tile(s + 1);    // global loads of the next step fly under this step's MFMAs
         if (any) {
             const __bf16 *Ah = Gh + (wm * 64 + fr) * LDB + 8 * fh;
-            const __bf16 *Bh = Xh + (wn * 64 + fr) * LDB + 8 * fh;
+            const __bf16 *Bh = Xh + (wn * (TN / 2) + fr) * LDB + 8 * fh;
 #pragma unroll
             for (int ks = 0; ks < KB3 / 16; ++ks) {
-                bf16x8 ah[2], al[2], bh[2], bl[2];
+                bf16x8 ah[2], al[2], bh[NJ], bl[NJ];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     ah[i] = *reinterpret_cast<const bf16x8 *>(Ah + i * 32 * LDB + ks * 16);
                     al[i] = *reinterpret_cast<const bf16x8 *>(Ah + T * LDB + i * 32 * LDB + ks * 16);
-                    bh[i] = *reinterpret_cast<const bf16x8 *>(Bh + i * 32 * LDB + ks * 16);
-                    bl[i] = *reinterpret_cast<const bf16x8 *>(Bh + T * LDB + i * 32 * LDB + ks * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    bh[j] = *reinterpret_cast<const bf16x8 *>(Bh + j * 32 * LDB + ks * 16);
+                    bl[j] = *reinterpret_cast<const bf16x8 *>(Bh + TN * LDB + j * 32 * LDB + ks * 16);
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < NJ; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
@@ -470,8 +475,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_b3(const WgradArgsB3 a) {
         }
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int ci = ci0 + wn * 64 + j * 32 + fr;
+    for (int j = 0; j < NJ; ++j) {
+        const int ci = ci0 + wn * (TN / 2) + j * 32 + fr;
         if (ci < a.Cin) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -486,10 +491,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_b3(const WgradArgsB3 a) {
 }
 
 int launch_wgrad_b3(const float *in, int in_rows, int Cin, const float *go, int out_rows, int Cout, int taps, const rd_conv_index *idx, float *gw,
-                    int rows_per_block, int64_t chunks, int tiles, hipStream_t st) {
+                    int rows_per_block, int64_t chunks, int tiles, int cin_tile, hipStream_t st) {
     WgradArgsB3 a{in, in_rows, Cin, go, out_rows, Cout, taps, *idx, gw, rows_per_block};
     dim3 grid((unsigned)chunks, (unsigned)tiles);
-    if (idx->mode == 3) k_conv_wgrad_b3<true><<<grid, 256, 0, st>>>(a);
-    else k_conv_wgrad_b3<false><<<grid, 256, 0, st>>>(a);
+    if (cin_tile == 128) {
+        if (idx->mode == 3) k_conv_wgrad_b3<true, 128><<<grid, 256, 0, st>>>(a);
+        else k_conv_wgrad_b3<false, 128><<<grid, 256, 0, st>>>(a);
+    } else {
+        if (idx->mode == 3) k_conv_wgrad_b3<true, 64><<<grid, 256, 0, st>>>(a);
+        else k_conv_wgrad_b3<false, 64><<<grid, 256, 0, st>>>(a);
+    }
     return RD_OK;
 }
