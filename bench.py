@@ -217,7 +217,7 @@ def main():
             # every algorithmic multiply-add is three bf16 MFMA products (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi): price the kernel
             # against the dense bf16 MFMA peak with the flops it really issues
             kname, pmc_key, peak = ("k_conv_igemm_b3<128,128,false> (gathered implicit-GEMM conv: sparse + dense 3x3 / 1x1 / transposed; fp32 operands "
-                                    "split to bf16 hi+lo in LDS, 3 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate)"), "k_conv_igemm_b3<128, 128, false>", PEAK_BF16_MFMA_TFLOPS
+                                    "split to bf16 hi+lo in LDS, 3 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate)"), "k_conv_igemm_b3<128, 128, false, false>", PEAK_BF16_MFMA_TFLOPS
             algorithmic, achieved = achieved, 3.0 * achieved
         else:
             kname, pmc_key, peak = ("k_conv_igemm<128,128,2,2,false> (gathered implicit-GEMM conv: sparse + dense 3x3 / 1x1 / transposed, exact fp32 MFMA)",
@@ -225,7 +225,7 @@ def main():
             algorithmic = achieved
         traffic = None          # HBM bytes per launch from the committed PMC passes (cannot be collected live inside bench.py)
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_hbm_traffic.json")))["kernels"]
+            pm = json.load(open(os.path.join(ROOT, "profiles", f"round1_pmc_hbm_traffic_{args.math}.json")))["kernels"]
             traffic = next(v["hbm_bytes_per_launch_corrected"] for k, v in pm.items() if pmc_key in k)
         except Exception:
             pass
