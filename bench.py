@@ -108,9 +108,11 @@ def main():
     world, rank, local_rank = D.env_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    D.init_distributed(backend="nccl", device=device)                 # "nccl" is RCCL on ROCm
+    dev_index = local_rank % torch.cuda.device_count()                # as tools/train.py:176 of the reference
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    # "nccl" is RCCL on ROCm.  RD_DIST_BACKEND=gloo lets two ranks share ONE GPU to rehearse the DDP path on a 1-GPU box
+    D.init_distributed(backend=os.environ.get("RD_DIST_BACKEND", "nccl"), device=device)
     from radardistill_amd import kernels as K
     from radardistill_amd import native
     from radardistill_amd.pcdet.models import model_fn_decorator
@@ -125,7 +127,7 @@ def main():
     optimizer = build_optimizer(model, cfg.OPTIMIZATION)
     total_steps = args.steps + args.warmup
     sched, _ = build_scheduler(optimizer, max(total_steps, 10), 1, -1, cfg.OPTIMIZATION)
-    run_model = D.wrap_ddp(model, local_rank)
+    run_model = D.wrap_ddp(model, dev_index)
     model_func = model_fn_decorator()
     # a few distinct batches per rank, resident in HBM before timing; sample sharding: seed depends on the rank
     batches = [device_batch(make_batch(batch_size=args.batch, n_lidar=35000, n_radar=2000, n_boxes=30, grid=args.grid,
