@@ -299,6 +299,20 @@ int rd_nconv_dgrad(const float *grad_out, const float *weight, int B, int H, int
 int rd_nconv_wgrad(const float *y, int ldy, const float *grad_out, int B, int H, int W, int NO, int NB, const int32_t *cin_off,
                    const int32_t *col_off, const int32_t *n_out, float *grad_w, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * M. Inference post-processing: rotated-BEV NMS and pairwise BEV overlap.
+ *    rd_nms_bev replaces iou3d_nms_cuda.nms_gpu (pcdet/ops/iou3d_nms/src/iou3d_nms.cpp:137-183, nms_kernel
+ *    iou3d_nms_kernel.cu:295-340; Python wrapper iou3d_nms_utils.nms_gpu:119-137): boxes (n,7) [x,y,z,dx,dy,dz,heading]
+ *    sorted by descending score; box j is suppressed by a kept box i < j when iou_bev(i, j) > thresh.  keep[0..*num_keep) =
+ *    indices of the kept boxes in ascending order; both stay in DEVICE memory (the reference copies the n*n/8-byte bit matrix
+ *    to the host and finishes on the CPU).  mask_ws: rd_nms_ws_bytes(n) bytes of scratch.
+ *    rd_boxes_overlap_bev replaces boxes_overlap_bev_gpu (iou3d_nms.cpp:29-48): ans (na, nb) overlap areas (recall records).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t rd_nms_ws_bytes(int n);
+int rd_nms_bev(int n, const float *boxes_sorted, float thresh, void *mask_ws, int64_t ws_bytes, int64_t *keep, int32_t *num_keep,
+               void *stream);
+int rd_boxes_overlap_bev(int na, const float *boxes_a, int nb, const float *boxes_b, float *ans_overlap, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,6 +9,7 @@
  * tests/test_oracle_iou3d.py.  Built by oracle/Makefile into oracle/_build/liboracle_iou3d.so.
  */
 #include <math.h>
+#include <stdlib.h>
 
 typedef struct { float x, y; } pt;
 
@@ -97,4 +98,33 @@ static float box_overlap(const float *a, const float *b) {
 /* boxes_a, boxes_b: (n, 7) [x, y, z, dx, dy, dz, heading]; out: (n,) BEV overlap area of pair i. */
 void oracle_boxes_aligned_overlap_bev(int n, const float *boxes_a, const float *boxes_b, float *out) {
     for (int i = 0; i < n; i++) out[i] = box_overlap(boxes_a + 7 * i, boxes_b + 7 * i);
+}
+
+/* (na, nb) overlap matrix: boxes_overlap_kernel (iou3d_nms_kernel.cu:236-249). */
+void oracle_boxes_overlap_bev(int na, const float *boxes_a, int nb, const float *boxes_b, float *out) {
+    for (int i = 0; i < na; i++)
+        for (int j = 0; j < nb; j++) out[(long)i * nb + j] = box_overlap(boxes_a + 7 * i, boxes_b + 7 * j);
+}
+
+/* iou_bev (iou3d_nms_kernel.cu:227-234). */
+static float iou_bev(const float *a, const float *b) {
+    float sa = a[3] * a[4], sb = b[3] * b[4];
+    float so = box_overlap(a, b);
+    return so / fmaxf(sa + sb - so, 1e-8f);
+}
+
+/* nms_gpu (iou3d_nms.cpp:137-183 over nms_kernel, iou3d_nms_kernel.cu:295-340): boxes sorted by descending score; box j > i is
+ * suppressed by a KEPT box i when iou_bev(i, j) > thresh.  The 64-wide bit matrix of the reference is only a storage format;
+ * the greedy decision below is the same.  keep: indices of kept boxes (ascending); returns their number. */
+int oracle_nms_bev(int n, const float *boxes, float thresh, long *keep) {
+    unsigned char *removed = (unsigned char *)calloc(n > 0 ? n : 1, 1);
+    int cnt = 0;
+    for (int i = 0; i < n; i++) {
+        if (removed[i]) continue;
+        keep[cnt++] = i;
+        for (int j = i + 1; j < n; j++)
+            if (!removed[j] && iou_bev(boxes + 7 * i, boxes + 7 * j) > thresh) removed[j] = 1;
+    }
+    free(removed);
+    return cnt;
 }

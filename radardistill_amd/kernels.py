@@ -566,6 +566,33 @@ def nconv_wgrad(y, grad_out, B, H, W, tab):
     return gw
 
 
+# ------------------------------------------------------------------------------------------ inference post-processing
+def nms_bev(boxes_sorted, thresh):
+    """boxes (n, 7) sorted by descending score -> (keep (n,) int64 device, num_keep 0-d int32 device): rotated-BEV greedy NMS,
+    no host round trip."""
+    _chk(boxes_sorted, f32, "nms boxes", 2)
+    n = boxes_sorted.shape[0]
+    if boxes_sorted.shape[1] != 7:
+        raise RuntimeError("nms_bev: boxes must be (n, 7)")
+    keep = torch.empty(n, dtype=torch.int64, device=boxes_sorted.device)
+    num = torch.zeros((), dtype=i32, device=boxes_sorted.device)
+    nb = native.lib().rd_nms_ws_bytes(n)
+    ws = torch.empty(max(nb // 8, 1), dtype=torch.int64, device=boxes_sorted.device)
+    check(native.lib().rd_nms_bev(n, _p(boxes_sorted), float(thresh), _p(ws), nb, _p(keep), _p(num), _stream()), "rd_nms_bev")
+    return keep, num
+
+
+def boxes_overlap_bev(boxes_a, boxes_b):
+    """(na, 7), (nb, 7) -> (na, nb) rotated BEV overlap areas."""
+    _chk(boxes_a, f32, "boxes_a", 2); _chk(boxes_b, f32, "boxes_b", 2)
+    if boxes_a.shape[1] != 7 or boxes_b.shape[1] != 7:
+        raise RuntimeError("boxes_overlap_bev: boxes must be (n, 7)")
+    out = torch.zeros((boxes_a.shape[0], boxes_b.shape[0]), dtype=f32, device=boxes_a.device)
+    check(native.lib().rd_boxes_overlap_bev(boxes_a.shape[0], _p(boxes_a), boxes_b.shape[0], _p(boxes_b), _p(out), _stream()),
+          "rd_boxes_overlap_bev")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ arithmetic mode of the conv kernels
 _CONV_MATH = ["f32"]
 

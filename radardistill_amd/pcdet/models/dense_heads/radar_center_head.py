@@ -474,7 +474,47 @@ class Radar_CenterHead(nn.Module):
         return loss, tb_dict
 
     def generate_predicted_boxes(self, batch_size, pred_dicts):
-        raise NotImplementedError("eval-time decode + rotated NMS is a 'next' row (SURVEY 8(f) rank 2), not on the training hot path")
+        """Eval-time decode + rotated NMS (radar_center_head.py:332-389): top-K peaks per head, box decode, score / range filter,
+        class-agnostic NMS on the device (rd_nms_bev), labels mapped to global ids (+1)."""
+        from ..model_utils import model_nms_utils
+        post_process_cfg = self.model_cfg.POST_PROCESSING
+        dev = pred_dicts[0]['hm'].device
+        post_center_limit_range = torch.tensor(post_process_cfg.POST_CENTER_LIMIT_RANGE, device=dev).float()
+        ret_dict = [{'pred_boxes': [], 'pred_scores': [], 'pred_labels': []} for _ in range(batch_size)]
+        for idx, pred_dict in enumerate(pred_dicts):
+            batch_hm = pred_dict['hm'].sigmoid()
+            batch_dim = pred_dict['dim'].exp()
+            batch_iou = None
+            if 'iou' in pred_dict.keys():
+                batch_iou = ((pred_dict['iou'].squeeze(dim=-1) + 1) * 0.5).type_as(batch_dim)
+            batch_rot_cos = pred_dict['rot'][:, 0].unsqueeze(dim=1)
+            batch_rot_sin = pred_dict['rot'][:, 1].unsqueeze(dim=1)
+            batch_vel = pred_dict['vel'] if 'vel' in self.separate_head_cfg.HEAD_ORDER else None
+            final_pred_dicts = centernet_utils.decode_bbox_from_heatmap(
+                heatmap=batch_hm, rot_cos=batch_rot_cos, rot_sin=batch_rot_sin, center=pred_dict['center'],
+                center_z=pred_dict['center_z'], dim=batch_dim, vel=batch_vel, iou=batch_iou,
+                rectifier=self.model_cfg.get("RECTIFIER", 0.), point_cloud_range=self.point_cloud_range, voxel_size=self.voxel_size,
+                feature_map_stride=self.feature_map_stride, K=post_process_cfg.MAX_OBJ_PER_SAMPLE,
+                circle_nms=(post_process_cfg.NMS_CONFIG.NMS_TYPE == 'circle_nms'), score_thresh=post_process_cfg.SCORE_THRESH,
+                post_center_limit_range=post_center_limit_range)
+            id_map = self.class_id_mapping_each_head[idx].to(dev)
+            for k, final_dict in enumerate(final_pred_dicts):
+                final_dict['pred_labels'] = id_map[final_dict['pred_labels'].long()]
+                if post_process_cfg.NMS_CONFIG.NMS_TYPE != 'circle_nms':
+                    selected, selected_scores = model_nms_utils.class_agnostic_nms(
+                        box_scores=final_dict['pred_scores'], box_preds=final_dict['pred_boxes'],
+                        nms_config=post_process_cfg.NMS_CONFIG, score_thresh=None)
+                    final_dict['pred_boxes'] = final_dict['pred_boxes'][selected]
+                    final_dict['pred_scores'] = selected_scores
+                    final_dict['pred_labels'] = final_dict['pred_labels'][selected]
+                ret_dict[k]['pred_boxes'].append(final_dict['pred_boxes'])
+                ret_dict[k]['pred_scores'].append(final_dict['pred_scores'])
+                ret_dict[k]['pred_labels'].append(final_dict['pred_labels'])
+        for k in range(batch_size):
+            ret_dict[k]['pred_boxes'] = torch.cat(ret_dict[k]['pred_boxes'], dim=0)
+            ret_dict[k]['pred_scores'] = torch.cat(ret_dict[k]['pred_scores'], dim=0)
+            ret_dict[k]['pred_labels'] = torch.cat(ret_dict[k]['pred_labels'], dim=0) + 1
+        return ret_dict
 
     # ------------------------------------------------------------------ forward
     def head_forward(self, spatial_features_2d):
@@ -507,6 +547,8 @@ class Radar_CenterHead(nn.Module):
             data_dict['lidar_pred_dicts'] = pred_dicts
             return data_dict
         self.forward_ret_dict['pred_dicts'] = pred_dicts
-        if not self.training or self.predict_boxes_when_training:
-            raise NotImplementedError("inference decode / ROI refinement are not part of the distill training path")
+        if self.predict_boxes_when_training and self.training:
+            raise NotImplementedError("ROI refinement (two-stage heads) is out of scope: SURVEY section 2")
+        if not self.training:
+            data_dict['final_box_dicts'] = self.generate_predicted_boxes(data_dict['batch_size'], pred_dicts)
         return data_dict

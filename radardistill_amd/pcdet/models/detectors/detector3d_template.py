@@ -142,6 +142,39 @@ class Detector3DTemplate(nn.Module):
         raise NotImplementedError
 
     # ---- checkpoints (detector3d_template.py:411-496)
+    @staticmethod
+    def generate_recall_record(box_preds, recall_dict, batch_index, data_dict=None, thresh_list=None):
+        """detector3d_template.py:367-409: how many ground-truth boxes have a prediction above each 3-D IoU threshold (the pairwise
+        IoU runs on the HIP overlap kernel; one host read per threshold, as in the reference)."""
+        from ...ops.iou3d_nms import iou3d_nms_utils
+        if 'gt_boxes' not in data_dict:
+            return recall_dict
+        rois = data_dict['rois'][batch_index] if 'rois' in data_dict else None
+        gt_boxes = data_dict['gt_boxes'][batch_index]
+        if recall_dict.__len__() == 0:
+            recall_dict = {'gt': 0}
+            for cur_thresh in thresh_list:
+                recall_dict['roi_%s' % (str(cur_thresh))] = 0
+                recall_dict['rcnn_%s' % (str(cur_thresh))] = 0
+        cur_gt = gt_boxes
+        nonzero = (cur_gt.sum(dim=1) != 0).nonzero()
+        k = int(nonzero.max().item()) if nonzero.numel() else -1          # trailing all-zero rows are padding
+        cur_gt = cur_gt[:k + 1]
+        if cur_gt.shape[0] > 0:
+            if box_preds.shape[0] > 0:
+                iou3d_rcnn = iou3d_nms_utils.boxes_iou3d_gpu(box_preds[:, 0:7], cur_gt[:, 0:7])
+            else:
+                iou3d_rcnn = torch.zeros((0, cur_gt.shape[0]))
+            if rois is not None:
+                iou3d_roi = iou3d_nms_utils.boxes_iou3d_gpu(rois[:, 0:7], cur_gt[:, 0:7])
+            for cur_thresh in thresh_list:
+                if iou3d_rcnn.shape[0] > 0:
+                    recall_dict['rcnn_%s' % str(cur_thresh)] += (iou3d_rcnn.max(dim=0)[0] > cur_thresh).sum().item()
+                if rois is not None:
+                    recall_dict['roi_%s' % str(cur_thresh)] += (iou3d_roi.max(dim=0)[0] > cur_thresh).sum().item()
+            recall_dict['gt'] += cur_gt.shape[0]
+        return recall_dict
+
     def _load_state_dict(self, model_state_disk, *, strict=True):
         state_dict = self.state_dict()
         spconv_keys = find_all_spconv_keys(self)

@@ -213,9 +213,40 @@ def g5_conv5():
     save("g5_conv5.npz", **out)
 
 
+def g6_decode():
+    """Eval path of the reference head: generate_predicted_boxes -> decode_bbox_from_heatmap -> class_agnostic_nms, with the absent
+    iou3d extension bridged by the oracle's C restatement of nms_gpu (so the rotated-overlap arithmetic is not pinned here)."""
+    from oracle import post as opost
+    L.install()
+    L._stub("pcdet.ops.iou3d_nms.iou3d_nms_utils", boxes_aligned_iou3d_gpu=ohead.boxes_aligned_iou3d, nms_gpu=opost.nms_gpu)
+    L.load("pcdet.models.model_utils.centernet_utils")
+    sys.modules.pop("pcdet.models.model_utils.model_nms_utils", None)      # the loader's inert placeholder -> the real leaf file
+    L.load("pcdet.models.model_utils.model_nms_utils")
+    sys.modules["pcdet.utils.box_utils"].bbox3d_overlaps_diou = sys.modules[
+        "pcdet.models.model_utils.centernet_utils"].bbox3d_overlaps_diou
+    mod = L.load("pcdet.models.dense_heads.radar_center_head")
+    pc_range, voxel, grid = bench_geometry(128)
+    m = mod.Radar_CenterHead(L.AttrDict(HEAD_CFG), input_channels=256, num_class=10, class_names=CLASS_NAMES,
+                             grid_size=grid, point_cloud_range=pc_range, voxel_size=voxel,
+                             predict_boxes_when_training=False)
+    sd = m.state_dict(); seeded_fill_(sd, seed=14); m.load_state_dict(sd)
+    g = np.random.default_rng(26)
+    feat = torch.from_numpy(g.normal(0, 1, size=(2, 256, 16, 16)).astype(np.float32))
+    m.eval()
+    d = m({"radar_spatial_features_2d": feat, "batch_size": 2})
+    out = {}
+    for h, pd in enumerate(m.forward_ret_dict["pred_dicts"]):
+        for k, v in pd.items():
+            out[f"pred_{h}_{k}"] = v.detach()
+    for b, fd in enumerate(d["final_box_dicts"]):
+        out[f"boxes_{b}"] = fd["pred_boxes"]; out[f"scores_{b}"] = fd["pred_scores"]; out[f"labels_{b}"] = fd["pred_labels"]
+        print("sample", b, "detections", tuple(fd["pred_boxes"].shape))
+    save("g6_decode.npz", **out)
+
+
 if __name__ == "__main__":
     torch.set_grad_enabled(False)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
-    fns = {"g1": g1_vfe, "g2": g2_dense_enc, "g3": g3_radar_distill, "g4": g4_center_head, "g5": g5_conv5}
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    fns = {"g1": g1_vfe, "g2": g2_dense_enc, "g3": g3_radar_distill, "g4": g4_center_head, "g5": g5_conv5, "g6": g6_decode}
     for w in which:
         fns[w]()

@@ -403,3 +403,102 @@ def test_bf16x3_conv_math_parity(golden_dir):
         test_full_distillation_step_vs_oracle(grad_tol=1.5e-1, tensor_tol=3e-1)
     finally:
         K.set_conv_math("f32")
+
+
+# ------------------------------------------------------------------------------------------ inference post-processing (8(f) rank 2)
+def _clustered_boxes(n, seed):
+    g = np.random.default_rng(seed)
+    k = max(1, n // 6)
+    centres = g.uniform(-40, 40, size=(k, 2))
+    c = centres[g.integers(0, k, size=n)] + g.normal(0, 1.2, size=(n, 2))
+    boxes = np.concatenate([c, g.normal(0, 0.5, size=(n, 1)), g.uniform(1.5, 5.0, size=(n, 1)), g.uniform(0.8, 2.5, size=(n, 1)),
+                            g.uniform(1.0, 2.5, size=(n, 1)), g.uniform(-np.pi, np.pi, size=(n, 1))], axis=1).astype(np.float32)
+    scores = g.uniform(0.05, 1.0, size=n).astype(np.float32)
+    return torch.from_numpy(boxes), torch.from_numpy(scores)
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 1000, 4200])
+def test_rotated_nms_vs_oracle(n):
+    """rd_nms_bev (bit matrix + greedy pass both on the device) vs the C restatement: the kept index list is bit-exact."""
+    from oracle import post
+    from radardistill_amd.pcdet.ops.iou3d_nms import iou3d_nms_utils as U
+    boxes, scores = _clustered_boxes(n, 100 + n)
+    kept = {}
+    for thresh in (0.2, 0.55):
+        keep, _ = U.nms_gpu(boxes.to(DEV), scores.to(DEV), thresh)
+        ref, _ = post.nms_gpu(boxes, scores, thresh)
+        assert keep.dtype == torch.int64 and keep.cpu().tolist() == ref.tolist(), (n, thresh, len(ref))
+        kept[thresh] = len(ref)
+    if n >= 64:
+        keep, _ = U.nms_gpu(boxes.to(DEV), scores.to(DEV), 0.2, pre_maxsize=50)
+        assert keep.cpu().tolist() == post.nms_gpu(boxes, scores, 0.2, pre_maxsize=50)[0].tolist()
+    if n >= 1000:
+        assert 0 < kept[0.2] < kept[0.55] < n        # the test data really exercises suppression
+
+
+def test_pairwise_iou3d_vs_oracle():
+    from oracle import post
+    from radardistill_amd.pcdet.ops.iou3d_nms import iou3d_nms_utils as U
+    a, _ = _clustered_boxes(70, 7)
+    b, _ = _clustered_boxes(33, 7)
+    close(U.boxes_iou3d_gpu(a.to(DEV), b.to(DEV)), post.boxes_iou3d(a, b), rtol=1e-4, atol=1e-5)
+    assert U.boxes_iou3d_gpu(a[:0].to(DEV), b.to(DEV)).shape == (0, 33)
+
+
+def test_center_head_eval_decode_golden(golden_dir):
+    """Eval path of the head (batched branches -> top-K decode -> rotated NMS on the device) vs the reference head's own output."""
+    g = np.load(f"{golden_dir}/g6_decode.npz")
+    m = _head()
+    m.eval()
+    r = np.random.default_rng(26)
+    feat = torch.from_numpy(r.normal(0, 1, size=(2, 256, 16, 16)).astype(np.float32))
+    with torch.no_grad():
+        d = m({"radar_spatial_features_2d": _cl(feat), "batch_size": 2})
+    for h, pd in enumerate(m.forward_ret_dict["pred_dicts"]):
+        for k, v in pd.items():
+            close(v, g[f"pred_{h}_{k}"], what=f"pred {h} {k}")
+    def canon(boxes, scores, labels):
+        # detections come out in descending-score order per head; scores 1e-6 apart may swap places between two fp32
+        # implementations (torch.topk leaves ties open in the reference too), so compare them as a SET: order by (label, x, y)
+        key = np.lexsort((np.round(boxes[:, 1], 3), np.round(boxes[:, 0], 3), labels))
+        return boxes[key], scores[key], labels[key]
+
+    for b, fd in enumerate(d["final_box_dicts"]):
+        assert fd["pred_boxes"].shape == g[f"boxes_{b}"].shape, (fd["pred_boxes"].shape, g[f"boxes_{b}"].shape)
+        hb, hs, hl = canon(fd["pred_boxes"].cpu().numpy(), fd["pred_scores"].cpu().numpy(), fd["pred_labels"].cpu().numpy())
+        gb, gsc, gl = canon(g[f"boxes_{b}"], g[f"scores_{b}"], g[f"labels_{b}"])
+        assert np.array_equal(hl, gl)
+        close(hb, gb, what="boxes")
+        close(hs, gsc, what="scores")
+        # and the order itself is descending in score within each head's block, up to that fp noise
+        sc = fd["pred_scores"].cpu().numpy(); lab = fd["pred_labels"].cpu().numpy()
+        assert np.all(np.diff(sc)[np.diff(np.searchsorted([1, 2, 4, 6, 7, 9, 11], lab, side="right")) == 0] <= 1e-5)
+
+
+def test_pillarnet_eval_forward_and_recall():
+    """model.eval(): the whole student + teacher chain, decode, NMS and the recall records; the records are re-derived with the
+    oracle's pairwise IoU from the predicted boxes."""
+    from oracle import post
+    grid, B = 128, 2
+    model, cfg, pc_range, voxel, gs = _build_pillarnet(grid)
+    sd = model.state_dict(); seeded_fill_(sd, seed=77); model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    batch = make_batch(batch_size=B, n_lidar=300, n_radar=700, n_boxes=10, grid=grid, seed=5)
+    from radardistill_amd.pcdet.models import load_data_to_gpu
+    bd = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in batch.items()}
+    load_data_to_gpu(bd)
+    with torch.no_grad():
+        pred_dicts, recall = model(bd)
+    assert len(pred_dicts) == B
+    tl = list(cfg.MODEL.POST_PROCESSING.RECALL_THRESH_LIST)
+    want = {"gt": 0, **{f"rcnn_{t}": 0 for t in tl}}
+    for b in range(B):
+        pb = pred_dicts[b]
+        assert pb["pred_boxes"].shape[0] == pb["pred_scores"].shape[0] == pb["pred_labels"].shape[0]
+        assert pb["pred_boxes"].shape[0] <= 6 * cfg.MODEL.RADAR_DENSE_HEAD.POST_PROCESSING.NMS_CONFIG.NMS_POST_MAXSIZE
+        if pb["pred_labels"].numel():
+            assert int(pb["pred_labels"].min()) >= 1 and int(pb["pred_labels"].max()) <= 10
+        rec = post.recall_record(pb["pred_boxes"].cpu(), torch.from_numpy(batch["gt_boxes"][b]), tl)
+        for k in want:
+            want[k] += rec[k]
+    assert {k: recall[k] for k in want} == want

@@ -190,3 +190,21 @@ def test_g5_conv5(golden_dir):
         y = sparse.dense_basic_block(y, sd, "1.", tr)
         y = sparse.dense_basic_block(y, sd, "2.", tr)
         _close(y, g[f"{mode}_x_conv5"], 2e-4, 2e-5)
+
+
+def test_g6_decode_and_nms(golden_dir):
+    """oracle.post.generate_predicted_boxes (loop restatement) vs the reference head's own eval path on the same raw maps."""
+    from oracle import post
+    from oracle.pillarnet import CLASS_NAMES, HEADS
+    from tests.golden.head_cfg import HEAD_CFG
+    g = np.load(f"{golden_dir}/g6_decode.npz")
+    pc_range, voxel, gs = bench_geometry(128)
+    names = ["center", "center_z", "dim", "rot", "vel", "iou", "hm"]
+    preds = [{k: torch.from_numpy(g[f"pred_{h}_{k}"]) for k in names} for h in range(6)]
+    id_map = [torch.tensor([CLASS_NAMES.index(n) for n in hn]) for hn in HEADS]
+    out = post.generate_predicted_boxes(preds, id_map, HEAD_CFG["POST_PROCESSING"], 8, voxel, pc_range, rectifier=HEAD_CFG["RECTIFIER"])
+    for b in range(2):
+        assert out[b]["pred_boxes"].shape == g[f"boxes_{b}"].shape
+        assert np.array_equal(out[b]["pred_labels"].numpy(), g[f"labels_{b}"])
+        _close(out[b]["pred_boxes"], g[f"boxes_{b}"], rtol=1e-5, atol=1e-5)
+        _close(out[b]["pred_scores"], g[f"scores_{b}"], rtol=1e-5, atol=1e-6)

@@ -136,3 +136,28 @@ def test_one_cycle_and_adam_step():
         q.data.mul_(1 - 0.01 * 3e-4); opt.step()
         optim.adam_true_wd_step([pp], [grad * step], [m], [v], step, 3e-4, 0.93)
     np.testing.assert_allclose(pp.numpy(), q.detach().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_nms_and_pairwise_iou_known_answers():
+    """Greedy rotated NMS (iou3d_nms.cpp:137-183) and pairwise 3-D IoU (iou3d_nms_utils.py:55-81) on hand-checkable boxes."""
+    from oracle import post
+    b = torch.tensor([[0.0, 0, 0, 4, 2, 2, 0],      # kept
+                      [1.0, 0, 0, 4, 2, 2, 0],      # overlap 3x2=6 with box 0: iou 6/(8+8-6)=0.6 -> suppressed at 0.5
+                      [2.0, 0, 0, 4, 2, 2, 0],      # overlap with box 0: 2x2=4 -> iou 1/3 -> kept; it then suppresses nothing new
+                      [20.0, 5, 0, 4, 2, 2, 0.3],   # far away, kept
+                      [20.0, 5, 0, 4, 2, 2, 0.3]])  # duplicate of box 3 -> suppressed
+    assert post.nms_bev_sorted(b, 0.5).tolist() == [0, 2, 3]
+    assert post.nms_bev_sorted(b, 0.7).tolist() == [0, 1, 2, 3]            # 0.6 is below the threshold now
+    assert post.nms_bev_sorted(b, 0.3).tolist() == [0, 3]                  # 1/3 > 0.3: box 2 goes too
+    assert post.nms_bev_sorted(b[:0], 0.5).tolist() == []
+    # box 1 is suppressed by box 0, so it must NOT suppress box 2 (iou(1,2) = 0.6): greedy, not transitive
+    iou = post.boxes_iou3d(b[:3], b[:3])
+    np.testing.assert_allclose(iou.numpy(), [[1, 0.6, 1 / 3], [0.6, 1, 0.6], [1 / 3, 0.6, 1]], rtol=1e-5)
+    # height overlap: shift z by 1 of 2 -> 3-D overlap halves: 8/(16+16-8)
+    c = b[:1].clone(); c[0, 2] = 1.0
+    np.testing.assert_allclose(post.boxes_iou3d(b[:1], c).numpy(), [[8.0 / 24.0]], rtol=1e-5)
+    scores = torch.tensor([0.9, 0.8, 0.7, 0.95, 0.1])
+    keep, _ = post.nms_gpu(b, scores, 0.5)
+    assert keep.tolist() == [3, 0, 2]                                      # descending score order of the survivors
+    rec = post.recall_record(b[[0, 3]], torch.cat([b[[1, 3]], torch.zeros(2, 7)]), [0.3, 0.5, 0.7])
+    assert rec == {"gt": 2, "rcnn_0.3": 2, "rcnn_0.5": 2, "rcnn_0.7": 1}
