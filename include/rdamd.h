@@ -313,6 +313,30 @@ int rd_nms_bev(int n, const float *boxes_sorted, float thresh, void *mask_ws, in
                void *stream);
 int rd_boxes_overlap_bev(int na, const float *boxes_a, int nb, const float *boxes_b, float *ans_overlap, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * N. Padded-voxel input format: hard voxeliser, PillarVFE, (PointPillarScatter = rd_rows_to_dense).
+ *    rd_voxelize_hard replaces DataProcessor.transform_points_to_voxels -> VoxelGeneratorWrapper -> spconv Point2VoxelCPU3d
+ *    (pcdet/datasets/processor/data_processor.py:16-61,142-229), batched: points (N, 1+C) [batch id, x, y, z, ...] sorted by
+ *    batch id.  Per sample, in point order: voxels are created by their first in-range point until max_voxels exist, every
+ *    voxel keeps its first max_points points.  Outputs (zero-filled inside, max_rows rows allocated by the caller,
+ *    max_rows >= batch * max_voxels is always enough): voxels (M, max_points, C), coords (M, 4) = (b, z, y, x),
+ *    num_points (M); *n_voxels = M (device).  Voxel order = sample, then first appearance; bit-exact vs the CPU algorithm.
+ *    rd_pillar_vfe_{stats,max} replace PillarVFE.forward with one PFNLayer (pcdet/models/backbones_3d/vfe/pillar_vfe.py:8-123):
+ *    stats[2*Cout] += (sum, sum of squares) of the Linear outputs over all real slots (BatchNorm1d batch statistics: divide by
+ *    M*P, padded slots are exact zeros); max: out (M, Cout) = max over the P slots of relu(lin*scale + shift).
+ *    weight (Cout, Cin) row-major (nn.Linear), Cin = (use_abs_xyz ? C : C-3) + 6 + with_distance, Cout <= 64, P <= 64.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t rd_voxelize_hard_ws_bytes(int n_points, int batch, int gx, int gy, int gz);
+int rd_voxelize_hard(const float *points, int n_points, int n_feat, int batch, int gx, int gy, int gz, float x0, float y0, float z0,
+                     float vx, float vy, float vz, int max_points, int max_voxels, int64_t max_rows, float *voxels, int32_t *coords,
+                     int32_t *num_points, int32_t *n_voxels, void *ws, int64_t ws_bytes, void *stream);
+int rd_pillar_vfe_stats(const float *voxels, const int32_t *num_points, const int32_t *coords, int M, int P, int C, const float *weight,
+                        int Cin, int Cout, int use_abs_xyz, int with_distance, float vx, float vy, float vz, float xoff, float yoff,
+                        float zoff, float *stats, void *stream);
+int rd_pillar_vfe_max(const float *voxels, const int32_t *num_points, const int32_t *coords, int M, int P, int C, const float *weight,
+                      int Cin, int Cout, int use_abs_xyz, int with_distance, float vx, float vy, float vz, float xoff, float yoff,
+                      float zoff, const float *scale, const float *shift, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

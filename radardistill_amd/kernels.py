@@ -566,6 +566,58 @@ def nconv_wgrad(y, grad_out, B, H, W, tab):
     return gw
 
 
+# ------------------------------------------------------------------------------------------ padded-voxel input format
+def voxelize_hard(points, batch, grid_xyz, pc_range, voxel_size, max_points, max_voxels):
+    """points (N, 1+C) [batch id, x, y, z, ...] sorted by batch id -> (voxels (M, max_points, C), coords (M, 4) int32 (b, z, y, x),
+    num_points (M,) int32): the capacity-limited voxeliser of the padded-voxel format, bit-exact vs spconv's CPU algorithm
+    (one host read: the voxel count M)."""
+    _chk(points, f32, "points", 2)
+    n, nf = points.shape[0], points.shape[1] - 1
+    gx, gy, gz = [int(v) for v in grid_xyz]
+    dev = points.device
+    rows = batch * int(max_voxels)
+    voxels = torch.empty((rows, int(max_points), nf), dtype=f32, device=dev)
+    coords = torch.empty((rows, 4), dtype=i32, device=dev)
+    num = torch.empty(rows, dtype=i32, device=dev)
+    m = torch.zeros((), dtype=i32, device=dev)
+    nb = native.lib().rd_voxelize_hard_ws_bytes(n, batch, gx, gy, gz)
+    ws = torch.empty(nb // 4, dtype=i32, device=dev)
+    check(native.lib().rd_voxelize_hard(_p(points), n, nf, batch, gx, gy, gz, float(pc_range[0]), float(pc_range[1]), float(pc_range[2]),
+                                        float(voxel_size[0]), float(voxel_size[1]), float(voxel_size[2]), int(max_points), int(max_voxels),
+                                        rows, _p(voxels), _p(coords), _p(num), _p(m), _p(ws), nb, _stream()), "rd_voxelize_hard")
+    M = int(m.item())
+    return voxels[:M], coords[:M], num[:M]
+
+
+def _pvfe_args(voxels, num_points, coords, weight, use_abs, with_dist):
+    _chk(voxels, f32, "voxels", 3); _chk(num_points, i32, "voxel_num_points", 1); _chk(coords, i32, "voxel_coords", 2); _chk(weight, f32, "weight", 2)
+    M, P, C = voxels.shape
+    if num_points.shape[0] != M or coords.shape != (M, 4):
+        raise RuntimeError("pillar_vfe: voxel_num_points / voxel_coords do not match voxels")
+    Cout, Cin = weight.shape
+    return M, P, C, Cin, Cout, int(bool(use_abs)), int(bool(with_dist))
+
+
+def pillar_vfe_stats(voxels, num_points, coords, weight, use_abs, with_dist, geom):
+    """-> stats (2*Cout,): sum and sum of squares of the PFN Linear outputs over all real slots (BatchNorm1d: n = M*P)."""
+    M, P, C, Cin, Cout, ua, wd = _pvfe_args(voxels, num_points, coords, weight, use_abs, with_dist)
+    stats = torch.zeros(2 * Cout, dtype=f32, device=voxels.device)
+    check(native.lib().rd_pillar_vfe_stats(_p(voxels), _p(num_points), _p(coords), M, P, C, _p(weight), Cin, Cout, ua, wd, *[float(v) for v in geom],
+                                           _p(stats), _stream()), "rd_pillar_vfe_stats")
+    return stats
+
+
+def pillar_vfe_max(voxels, num_points, coords, weight, use_abs, with_dist, geom, scale, shift):
+    """-> (M, Cout): max over the slots of relu(Linear * scale + shift)."""
+    M, P, C, Cin, Cout, ua, wd = _pvfe_args(voxels, num_points, coords, weight, use_abs, with_dist)
+    if _chk(scale, f32, "scale").numel() != Cout or _chk(shift, f32, "shift").numel() != Cout:
+        raise RuntimeError("pillar_vfe_max: scale / shift must have Cout elements")
+    out = torch.empty((M, Cout), dtype=f32, device=voxels.device)
+    check(native.lib().rd_pillar_vfe_max(_p(voxels), _p(num_points), _p(coords), M, P, C, _p(weight), Cin, Cout, ua, wd, *[float(v) for v in geom],
+                                         _p(scale), _p(shift), _p(out), _stream()), "rd_pillar_vfe_max")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ inference post-processing
 def nms_bev(boxes_sorted, thresh):
     """boxes (n, 7) sorted by descending score -> (keep (n,) int64 device, num_keep 0-d int32 device): rotated-BEV greedy NMS,

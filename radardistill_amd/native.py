@@ -79,6 +79,13 @@ SIGNATURES = {
     "rd_dwconv_wgrad_ws_bytes": (c_i64, [c_int, c_int, c_int, c_int, c_int]),
     "rd_dwconv_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_i64, _P]),
     "rd_center_targets": (c_int, [_P, c_int, c_int, c_int, ctypes.POINTER(TargetCfg), _P, _P, _P, _P, _P, _P]),
+    "rd_voxelize_hard_ws_bytes": (c_i64, [c_int, c_int, c_int, c_int, c_int]),
+    "rd_voxelize_hard": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_i64,
+                                 _P, _P, _P, _P, _P, c_i64, _P]),
+    "rd_pillar_vfe_stats": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32,
+                                    _P, _P]),
+    "rd_pillar_vfe_max": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32,
+                                  _P, _P, _P, _P]),
     "rd_nms_ws_bytes": (c_i64, [c_int]),
     "rd_nms_bev": (c_int, [c_int, _P, c_f32, _P, c_i64, _P, _P, _P]),
     "rd_boxes_overlap_bev": (c_int, [c_int, _P, c_int, _P, _P, _P]),

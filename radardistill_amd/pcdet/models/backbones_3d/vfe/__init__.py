@@ -1,4 +1,5 @@
 from .dynamic_pillar_vfe import DynamicPillarVFESimple2D, Radar_DynamicPillarVFESimple2D
+from .pillar_vfe import PillarVFE
 from .vfe_template import VFETemplate
 
 # registry keyed by the yaml NAME (pcdet/models/backbones_3d/vfe/__init__.py:9-21); only the distill-config entries
@@ -6,4 +7,5 @@ __all__ = {
     'VFETemplate': VFETemplate,
     'DynamicPillarVFESimple2D': DynamicPillarVFESimple2D,
     'Radar_DynamicPillarVFESimple2D': Radar_DynamicPillarVFESimple2D,
+    'PillarVFE': PillarVFE,                 # padded-voxel input format
 }

@@ -124,7 +124,15 @@ class Detector3DTemplate(nn.Module):
         return None, info
 
     def build_map_to_bev_module(self, model_info_dict):
-        return self._unsupported('MAP_TO_BEV', model_info_dict)
+        """detector3d_template.py:111-121: PointPillarScatter of the padded-voxel input format."""
+        cfg = self.model_cfg.get('MAP_TO_BEV', None)
+        if cfg is None:
+            return None, model_info_dict
+        from ..backbones_2d import map_to_bev
+        m = map_to_bev.__all__[cfg.NAME](model_cfg=cfg, grid_size=model_info_dict['grid_size'])
+        model_info_dict['module_list'].append(m)
+        model_info_dict['num_bev_features'] = m.num_bev_features
+        return m, model_info_dict
 
     def build_radar_map_to_bev_module(self, model_info_dict):
         return self._unsupported('RADAR_MAP_TO_BEV', model_info_dict)

@@ -244,9 +244,40 @@ def g6_decode():
     save("g6_decode.npz", **out)
 
 
+def g7_pillar():
+    """PillarVFE + PointPillarScatter of the reference on padded voxels produced by the oracle's voxeliser (spconv is absent)."""
+    from oracle import voxel as ovox
+    pv = L.load("pcdet.models.backbones_3d.vfe.pillar_vfe")
+    L._ns("pcdet.models.backbones_2d.map_to_bev", os.path.join(L.REF_ROOT, "pcdet/models/backbones_2d/map_to_bev"))
+    sc = L.load("pcdet.models.backbones_2d.map_to_bev.pointpillar_scatter")
+    pc_range, voxel, grid = bench_geometry(128)
+    voxel = [voxel[0], voxel[1], pc_range[5] - pc_range[2]]              # pillars: one cell in z
+    batch = make_batch(batch_size=2, n_lidar=1500, n_radar=16, n_boxes=2, grid=128, seed=8)
+    vox, coords, num = ovox.batch_points_to_voxels(batch["points"], 2, voxel, pc_range, max_points=8, max_voxels=700)
+    out = {}
+    for tag, use_abs, with_dist in (("a", True, False), ("b", False, True)):
+        cfg = L.AttrDict(USE_NORM=True, WITH_DISTANCE=with_dist, USE_ABSLOTE_XYZ=use_abs, NUM_FILTERS=[64])
+        m = pv.PillarVFE(cfg, num_point_features=5, voxel_size=voxel, point_cloud_range=pc_range)
+        sd = m.state_dict(); seeded_fill_(sd, seed=31); m.load_state_dict(sd)
+        for mode in ("eval", "train"):
+            m.train(mode == "train")
+            bd = {"voxels": torch.from_numpy(vox), "voxel_num_points": torch.from_numpy(num), "voxel_coords": torch.from_numpy(coords)}
+            bd = m(bd)
+            out[f"{tag}_{mode}_pillar_features"] = bd["pillar_features"]
+            if mode == "train":
+                out[f"{tag}_running_mean"] = m.pfn_layers[0].norm.running_mean.clone()
+                out[f"{tag}_running_var"] = m.pfn_layers[0].norm.running_var.clone()
+        if tag == "a":
+            s = sc.PointPillarScatter(L.AttrDict(NUM_BEV_FEATURES=64), grid_size=[int(grid[0]), int(grid[1]), 1])
+            m.eval()
+            bd = m({"voxels": torch.from_numpy(vox), "voxel_num_points": torch.from_numpy(num), "voxel_coords": torch.from_numpy(coords)})
+            out["spatial_features"] = s(bd)["spatial_features"]
+    save("g7_pillar.npz", **out)
+
+
 if __name__ == "__main__":
     torch.set_grad_enabled(False)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
-    fns = {"g1": g1_vfe, "g2": g2_dense_enc, "g3": g3_radar_distill, "g4": g4_center_head, "g5": g5_conv5, "g6": g6_decode}
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    fns = {"g1": g1_vfe, "g2": g2_dense_enc, "g3": g3_radar_distill, "g4": g4_center_head, "g5": g5_conv5, "g6": g6_decode, "g7": g7_pillar}
     for w in which:
         fns[w]()

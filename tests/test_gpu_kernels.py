@@ -409,3 +409,61 @@ def test_narrow_branch_convs_reject_bad_tables():
     tab5 = K.BranchTable([0], [0], [5])
     with pytest.raises(RuntimeError):
         K.nconv_fwd(y, torch.zeros((5, 64, 3, 3), device=DEV), None, 1, 8, 8, tab5)   # 5 outputs per branch: not supported
+
+
+# ------------------------------------------------------------------------------------------ padded-voxel input format (8(f) rank 3)
+@pytest.mark.parametrize("B,n_pts,max_points,max_voxels,gz", [(2, 1500, 8, 700, 1), (3, 4000, 5, 100000, 1), (1, 0, 4, 10, 1),
+                                                               (2, 3000, 3, 5000, 4)])
+def test_hard_voxelizer_bit_exact_vs_oracle(B, n_pts, max_points, max_voxels, gz):
+    """rd_voxelize_hard vs the sequential CPU algorithm: voxel order, slot order, truncation by both capacities -- all bit-exact."""
+    from oracle import voxel as ovox
+    from radardistill_amd.voxel import VoxelGenerator
+    pc_range, voxel, grid = bench_geometry(128)
+    voxel = [voxel[0], voxel[1], (pc_range[5] - pc_range[2]) / gz]
+    batch = make_batch(batch_size=B, n_lidar=n_pts, n_radar=16, n_boxes=2, grid=128, seed=20 + B)
+    pts = batch["points"] if n_pts else np.zeros((0, 6), dtype=np.float32)
+    if n_pts:
+        pts = pts.copy()
+        pts[::17, 1] += 40.0                            # some points outside the range
+        pts[5::29, 3] = pc_range[5]                      # exactly on the upper z bound: floor lands on grid size -> dropped
+    gen = VoxelGenerator(voxel, pc_range, 5, max_points, max_voxels)
+    v, c, n = gen.generate(torch.from_numpy(pts).to(DEV), batch_size=B)
+    rv, rc, rn = ovox.batch_points_to_voxels(pts, B, voxel, pc_range, max_points, max_voxels)
+    assert v.shape == rv.shape and c.dtype == torch.int32 and n.dtype == torch.int32
+    assert np.array_equal(c.cpu().numpy(), rc) and np.array_equal(n.cpu().numpy(), rn)
+    assert np.array_equal(v.cpu().numpy(), rv)           # copied point words: exact
+    if n_pts and max_voxels == 700:
+        assert rv.shape[0] == B * max_voxels             # the voxel cap really bites in this case
+
+
+def test_pillar_vfe_and_scatter_golden(golden_dir):
+    """PillarVFE (one fused PFN layer) + PointPillarScatter on HIP vs the reference modules' outputs."""
+    from oracle import voxel as ovox
+    from radardistill_amd.pcdet.config import AttrDict
+    from radardistill_amd.pcdet.models.backbones_3d.vfe import __all__ as VFE
+    from radardistill_amd.pcdet.models.backbones_2d.map_to_bev import __all__ as M2B
+    from radardistill_amd.voxel import VoxelGenerator
+    g = np.load(f"{golden_dir}/g7_pillar.npz")
+    pc_range, voxel, grid = bench_geometry(128)
+    voxel = [voxel[0], voxel[1], pc_range[5] - pc_range[2]]
+    batch = make_batch(batch_size=2, n_lidar=1500, n_radar=16, n_boxes=2, grid=128, seed=8)
+    v, c, n = VoxelGenerator(voxel, pc_range, 5, 8, 700).generate(torch.from_numpy(batch["points"]).to(DEV), batch_size=2)
+    for tag, use_abs, with_dist in (("a", True, False), ("b", False, True)):
+        m = VFE["PillarVFE"](AttrDict(USE_NORM=True, WITH_DISTANCE=with_dist, USE_ABSLOTE_XYZ=use_abs, NUM_FILTERS=[64]), num_point_features=5,
+                             voxel_size=voxel, point_cloud_range=pc_range)
+        sd = m.state_dict(); seeded_fill_(sd, seed=31); m.load_state_dict(sd); m = m.to(DEV)
+        for mode in ("eval", "train"):
+            m.train(mode == "train")
+            with torch.no_grad():
+                bd = m({"voxels": v, "voxel_num_points": n, "voxel_coords": c, "batch_size": 2})
+            close(bd["pillar_features"], g[f"{tag}_{mode}_pillar_features"], what=f"{tag} {mode}")
+        close(m.pfn_layers[0].norm.running_mean, g[f"{tag}_running_mean"]); close(m.pfn_layers[0].norm.running_var, g[f"{tag}_running_var"])
+        if tag == "a":
+            m.eval()
+            s = M2B["PointPillarScatter"](AttrDict(NUM_BEV_FEATURES=64), grid_size=[int(grid[0]), int(grid[1]), 1])
+            with torch.no_grad():
+                bd = s(m({"voxels": v, "voxel_num_points": n, "voxel_coords": c, "batch_size": 2}))
+            assert bd["spatial_features"].shape == (2, 64, 128, 128)
+            close(bd["spatial_features"], g["spatial_features"], what="scatter")
+    with pytest.raises(NotImplementedError):
+        m.train(); m({"voxels": v, "voxel_num_points": n, "voxel_coords": c})     # gradients requested: not built

@@ -208,3 +208,37 @@ def test_g6_decode_and_nms(golden_dir):
         assert np.array_equal(out[b]["pred_labels"].numpy(), g[f"labels_{b}"])
         _close(out[b]["pred_boxes"], g[f"boxes_{b}"], rtol=1e-5, atol=1e-5)
         _close(out[b]["pred_scores"], g[f"scores_{b}"], rtol=1e-5, atol=1e-6)
+
+
+def _g7_inputs():
+    from oracle import voxel as ovox
+    pc_range, voxel, grid = bench_geometry(128)
+    voxel = [voxel[0], voxel[1], pc_range[5] - pc_range[2]]
+    batch = make_batch(batch_size=2, n_lidar=1500, n_radar=16, n_boxes=2, grid=128, seed=8)
+    vox, coords, num = ovox.batch_points_to_voxels(batch["points"], 2, voxel, pc_range, max_points=8, max_voxels=700)
+    return batch, pc_range, voxel, grid, vox, coords, num
+
+
+def _pvfe_state(cin, seed=31):
+    sd = {"pfn_layers.0.linear.weight": torch.zeros(64, cin), "pfn_layers.0.norm.weight": torch.zeros(64), "pfn_layers.0.norm.bias": torch.zeros(64),
+          "pfn_layers.0.norm.running_mean": torch.zeros(64), "pfn_layers.0.norm.running_var": torch.ones(64),
+          "pfn_layers.0.norm.num_batches_tracked": torch.zeros((), dtype=torch.long)}
+    return seeded_fill_(sd, seed=seed)
+
+
+def test_g7_pillar_vfe_and_scatter(golden_dir):
+    """oracle.voxel.pillar_vfe / scatter vs the reference's PillarVFE / PointPillarScatter modules."""
+    from oracle import voxel as ovox
+    g = np.load(f"{golden_dir}/g7_pillar.npz")
+    batch, pc_range, voxel, grid, vox, coords, num = _g7_inputs()
+    v, n, c = torch.from_numpy(vox), torch.from_numpy(num), torch.from_numpy(coords)
+    for tag, use_abs, with_dist, cin in (("a", True, False, 11), ("b", False, True, 9)):
+        st = _pvfe_state(cin)
+        for mode in ("eval", "train"):
+            out = ovox.pillar_vfe(v, n, c, st, voxel, pc_range, use_abs, with_dist, training=(mode == "train"))
+            _close(out, g[f"{tag}_{mode}_pillar_features"], rtol=1e-4, atol=1e-5)
+    # the scatter fixture was produced after the train-mode forward above had updated the running statistics once
+    st = _pvfe_state(11)
+    st["pfn_layers.0.norm.running_mean"] = torch.from_numpy(g["a_running_mean"]); st["pfn_layers.0.norm.running_var"] = torch.from_numpy(g["a_running_var"])
+    feats = ovox.pillar_vfe(v, n, c, st, voxel, pc_range, True, False, training=False)
+    _close(ovox.scatter(feats, c, 2, int(grid[0]), int(grid[1])), g["spatial_features"], rtol=1e-4, atol=1e-5)

@@ -161,3 +161,25 @@ def test_nms_and_pairwise_iou_known_answers():
     assert keep.tolist() == [3, 0, 2]                                      # descending score order of the survivors
     rec = post.recall_record(b[[0, 3]], torch.cat([b[[1, 3]], torch.zeros(2, 7)]), [0.3, 0.5, 0.7])
     assert rec == {"gt": 2, "rcnn_0.3": 2, "rcnn_0.5": 2, "rcnn_0.7": 1}
+
+
+def test_hard_voxelizer_known_answers():
+    """spconv Point2VoxelCPU3d semantics: first-appearance voxel order, stream order inside a voxel, both capacities, range filter."""
+    from oracle import voxel as ovox
+    rng = [0.0, 0.0, -1.0, 4.0, 4.0, 1.0]
+    vs = [1.0, 1.0, 2.0]
+    pts = np.array([[2.5, 0.5, 0.0, 7.0],     # voxel A (x2,y0) created
+                    [0.5, 0.5, 0.0, 1.0],     # voxel B (x0,y0)
+                    [2.6, 0.4, 0.1, 8.0],     # A, slot 1
+                    [9.0, 0.5, 0.0, 0.0],     # outside -> dropped
+                    [2.7, 0.3, 0.2, 9.0],     # A full (max_points 2) -> dropped
+                    [3.5, 3.5, 0.0, 2.0],     # voxel C
+                    [1.5, 1.5, 0.0, 3.0],     # would be voxel D but max_voxels = 3 -> dropped
+                    [0.6, 0.6, 0.0, 4.0],     # B, slot 1
+                    [4.0, 0.5, 0.0, 5.0]],    # x == range max -> floor(4/1) = 4 == grid -> dropped
+                   dtype=np.float32)
+    v, c, n = ovox.points_to_voxels(pts, vs, rng, max_points=2, max_voxels=3)
+    assert c.tolist() == [[0, 0, 2], [0, 0, 0], [0, 3, 3]] and n.tolist() == [2, 2, 1]
+    assert v[0, :, 3].tolist() == [7.0, 8.0] and v[1, :, 3].tolist() == [1.0, 4.0] and v[2, :, 3].tolist() == [2.0, 0.0]
+    v0, c0, n0 = ovox.points_to_voxels(pts[:0], vs, rng, 2, 3)
+    assert v0.shape == (0, 2, 4) and c0.shape == (0, 3) and n0.shape == (0,)
