@@ -22,3 +22,59 @@ class SyntheticDistillDataset:
     def from_cfg(cls, cfg):
         d = cfg.DATA_CONFIG
         return cls(cfg.CLASS_NAMES, d.POINT_CLOUD_RANGE, d.VOXEL_SIZE, d.get('NUM_POINT_FEATURES', 5), d.get('RADAR_NUM_POINT_FEATURES', 6))
+
+
+def collate_batch(batch_list, _unused=False):
+    """Sample dicts -> batch dict, as NuScenesDataset_Distill.collate_batch (pcdet/datasets/dataset_distill.py:220-325) for the keys
+    of the distillation path: point / voxel-coordinate arrays get the sample index prepended as column 0 and are concatenated,
+    padded-voxel payloads are concatenated, `gt_boxes` is zero-padded to the longest sample, everything else is stacked.
+    Lists of arrays per sample (the DOUBLE_FLIP test-time augmentation) multiply `batch_size` by their length."""
+    from collections import defaultdict
+    data = defaultdict(list)
+    for sample in batch_list:
+        for k, v in sample.items():
+            data[k].append(v)
+    batch_size, ratio = len(batch_list), 1
+    ret = {}
+    for key, val in data.items():
+        if key in ('voxels', 'voxel_num_points', 'radar_voxels', 'radar_voxel_num_points'):
+            if isinstance(val[0], list):
+                ratio = len(val[0])
+                val = [i for item in val for i in item]
+            ret[key] = np.concatenate(val, axis=0)
+        elif key in ('points', 'voxel_coords', 'radar_points', 'radar_voxel_coords'):
+            if isinstance(val[0], list):
+                val = [i for item in val for i in item]
+            ret[key] = np.concatenate([np.pad(c, ((0, 0), (1, 0)), mode='constant', constant_values=i) for i, c in enumerate(val)], axis=0)
+        elif key == 'gt_boxes':
+            max_gt = max(len(x) for x in val)
+            out = np.zeros((batch_size, max_gt, val[0].shape[-1]), dtype=np.float32)
+            for k in range(batch_size):
+                out[k, :len(val[k]), :] = val[k]
+            ret[key] = out
+        elif key == 'calib':
+            ret[key] = val
+        else:
+            ret[key] = np.stack(val, axis=0)
+    ret['batch_size'] = batch_size * ratio
+    return ret
+
+
+class SyntheticSweeps(SyntheticDistillDataset):
+    """Map-style dataset of synthetic nuScenes-shaped sweeps (SURVEY 8(d) distributions) yielding the reference's per-sample dicts
+    (`points` (n,5), `radar_points` (m,6), `gt_boxes` (k,10), `frame_id`); use with torch DataLoader(collate_fn=collate_batch)."""
+
+    def __init__(self, length, grid=512, n_lidar=35000, n_radar=2000, n_boxes=30, seed=0, **kw):
+        from .synthetic import bench_geometry
+        pc_range, voxel, _ = bench_geometry(grid)
+        super().__init__(kw.pop('class_names', ['car', 'truck', 'construction_vehicle', 'bus', 'trailer', 'barrier', 'motorcycle', 'bicycle',
+                                                'pedestrian', 'traffic_cone']), pc_range, voxel, **kw)
+        self.length, self.grid, self.n_lidar, self.n_radar, self.n_boxes, self.seed = length, grid, n_lidar, n_radar, n_boxes, seed
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, index):
+        from .synthetic import make_batch
+        b = make_batch(batch_size=1, n_lidar=self.n_lidar, n_radar=self.n_radar, n_boxes=self.n_boxes, grid=self.grid, seed=self.seed + index)
+        return {'points': b['points'][:, 1:], 'radar_points': b['radar_points'][:, 1:], 'gt_boxes': b['gt_boxes'][0], 'frame_id': np.int64(index)}

@@ -165,3 +165,23 @@ def train_step(model, optimizer, lr_scheduler, model_func, batch, accumulated_it
     loss.backward()
     optimizer.step()
     return loss, tb_dict
+
+
+# ---------------------------------------------------------------------------------------------- checkpoints (train_utils.py:253-293)
+def model_state_to_cpu(model_state):
+    return type(model_state)((k, v.cpu()) for k, v in model_state.items())
+
+
+def checkpoint_state(model=None, optimizer=None, epoch=None, it=None):
+    """Same dictionary layout as the reference (`epoch`, `it`, `model_state`, `optimizer_state`, `version`), so checkpoints written
+    here load with the reference's load_params_from_file / load_params_with_optimizer and vice versa (state_dict names are equal)."""
+    optim_state = optimizer.state_dict() if optimizer is not None else None
+    model_state = None
+    if model is not None:
+        m = model.module if isinstance(model, torch.nn.parallel.DistributedDataParallel) else model
+        model_state = model_state_to_cpu(m.state_dict())
+    return {'epoch': epoch, 'it': it, 'model_state': model_state, 'optimizer_state': optim_state, 'version': 'radardistill_amd'}
+
+
+def save_checkpoint(state, filename='checkpoint'):
+    torch.save(state, '{}.pth'.format(filename))
