@@ -129,6 +129,19 @@ int rd_conv_fwd(const float *in, int in_rows, int Cin, const float *weight_k, in
 int rd_set_conv_math(int mode);
 int rd_get_conv_math(void);
 
+/* Pre-split operands for the bf16x3 kernels.  "Split format": every 16-byte group of 4 consecutive fp32 elements is replaced by
+ * [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] as bf16 (hi = bf16(x), lo = bf16(x - hi)) -- same size, same addressing, so a tensor is
+ * split ONCE (rd_split_bf16, or rd_weight_layout_split for weights) instead of once per tap, column tile and GEMM that reads it.
+ * rd_conv_fwd_split / rd_conv_wgrad_split are rd_conv_fwd / rd_conv_wgrad with a flag per operand saying which format it is in
+ * (bf16x3 mode only; an input sampled by a deformable index must stay fp32). */
+int rd_split_bf16(const float *x, int64_t n, void *out, void *stream);
+int rd_weight_layout_split(const float *src, void *dst, int Cout, int Cin, int taps, int kind, int flip, void *stream);
+int rd_conv_fwd_split(const void *in, int in_is_split, int in_rows, int Cin, const void *weight_k, int w_is_split, int taps,
+                      const float *bias, float *out, int out_rows, int Cout, const rd_conv_index *idx, const float *scale,
+                      const float *shift, const float *residual, int relu, float *stats, void *stream);
+int rd_conv_wgrad_split(const void *in, int in_is_split, int in_rows, int Cin, const void *grad_out, int go_is_split, int out_rows,
+                        int Cout, int taps, const rd_conv_index *idx, float *grad_wk, void *stream);
+
 /* Data gradient on the forward weights: grad_in[i][c] = sum_t sum_n grad_out[src_bwd(i,t)][n] * weight_k[n][t][c], with weight_k the
  * FORWARD kernel layout [Cout][taps][Cin] (the kernel reads it transposed; no re-laid-out copy) and idx the backward index
  * (transposed neighbour table / flip = 1 for sub-manifold, the transposed geometry for dense convolutions).  Cout % 32 == 0

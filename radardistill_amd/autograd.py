@@ -146,6 +146,48 @@ def kernel_weight(param, Cout, Cin, taps, kind, flip=False):
     return w
 
 
+# bf16x3 mode, optional (RD_PRESPLIT=1): operands are split into bf16 hi/lo ONCE per tensor (kernels.split_bf16 /
+# weight_layout_split) instead of inside every K step of every GEMM that reads them.  Measured (round 1): the GEMMs gain 3-11 %
+# (1.0 ms/step) but the stand-alone split passes cost 2.0 ms/step (139 + 108 launches), so it stays off until the split is fused
+# into the producing kernels' epilogues; results are bit-identical either way (tests/test_gpu_model.py).
+PRESPLIT = os.environ.get("RD_PRESPLIT", "0") == "1"
+_SPLIT_W_CACHE = {}
+
+
+def kernel_weight_split(param, wk, Cout, Cin, taps, kind2=False):
+    """Split-format copy of the kernel-layout weights `wk` of `param` (kind2: the [Cin][taps][Cout] data-gradient layout), cached per
+    parameter version like kernel_weight."""
+    def make():
+        return K.weight_layout_split(wk.contiguous(), Cout, Cin, taps, 2 if kind2 else 0, False)
+    if not param.is_leaf:
+        return make()
+    key = (id(param), kind2)
+    ver = (param._version, _WEIGHTS_EPOCH[0] if param.requires_grad else -1, param.data_ptr(), Cout, Cin, taps)
+    hit = _SPLIT_W_CACHE.get(key)
+    if hit is not None and hit[0] == ver and hit[2]() is param:
+        return hit[1]
+    w = make()
+    _SPLIT_W_CACHE[key] = (ver, w, weakref.ref(param))
+    return w
+
+
+def split_activation(x):
+    """Split-format copy of an activation / gradient tensor, remembered on the tensor object while it is unchanged."""
+    hit = getattr(x, "_rd_split", None)
+    if hit is not None and hit[0] == x._version and hit[1].data_ptr() != 0:
+        return hit[1]
+    xs = K.split_bf16(x)
+    try:
+        x._rd_split = (x._version, xs)
+    except Exception:
+        pass
+    return xs
+
+
+def _b3_presplit(Cin, Cout, mode):
+    return PRESPLIT and K.get_conv_math() == "bf16x3" and Cout > 32 and Cin % 4 == 0 and mode != 3
+
+
 class ConvSpec:
     """Geometry of one convolution call: how output rows find their input rows, forward and backward.
 
@@ -192,7 +234,13 @@ class _ConvFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, spec, Cout, stats):
         Cin = x.shape[1]
         wk = kernel_weight(weight, Cout, Cin, spec.taps, spec.param_kind)
-        out = K.conv_fwd(x, wk, spec.taps, bias, spec.out_rows, Cout, spec.fwd_ix, stats=stats, nbr_keepalive=spec.fwd_nbr)
+        ctx.xs = None
+        if _b3_presplit(Cin, Cout, spec.fwd_ix.mode):
+            ctx.xs = split_activation(x)              # reused by the weight gradient
+            out = K.conv_fwd(ctx.xs, kernel_weight_split(weight, wk, Cout, Cin, spec.taps), spec.taps, bias, spec.out_rows, Cout, spec.fwd_ix,
+                             stats=stats, nbr_keepalive=spec.fwd_nbr, in_split=True, w_split=True)
+        else:
+            out = K.conv_fwd(x, wk, spec.taps, bias, spec.out_rows, Cout, spec.fwd_ix, stats=stats, nbr_keepalive=spec.fwd_nbr)
         ctx.spec, ctx.Cout, ctx.Cin = spec, Cout, Cin
         ctx.has_bias = bias is not None
         ctx.wk = wk                                # kernel-layout weights of THIS step (the optimizer runs after backward)
@@ -212,6 +260,12 @@ class _ConvFn(torch.autograd.Function):
             # mode keeps the [Cin][taps][Cout] copy (rd_conv_dgrad itself works in both modes).
             if Cout % 32 == 0 and K.get_conv_math() == "f32":
                 gx = K.conv_dgrad(grad_out, wk, spec.taps, spec.in_rows, Cin, spec.bwd_ix, nbr_keepalive=spec.bwd_nbr)   # forward weights, read transposed
+            elif Cout % 32 == 0 and _b3_presplit(Cout, Cin, spec.bwd_ix.mode):
+                # bf16x3 with pre-split operands: grad_out is split once (shared with the weight gradient below), the weights are
+                # re-laid-out to [Cin][taps][Cout] and split in one launch
+                gos = split_activation(grad_out)
+                wds = kernel_weight_split(weight, wk, Cout, Cin, spec.taps, kind2=True)
+                gx = K.conv_fwd(gos, wds, spec.taps, None, spec.in_rows, Cin, spec.bwd_ix, nbr_keepalive=spec.bwd_nbr, in_split=True, w_split=True)
             else:
                 go, Cp = grad_out, Cout
                 if Cout % 32 != 0:      # narrow outputs (27-channel DCN offsets): zero-pad the contraction dim to the kernel's K step
@@ -229,7 +283,12 @@ class _ConvFn(torch.autograd.Function):
                     ref.index_add_(0, nb[o, t], grad_out[o].double() @ w3[:, t, :])
                 _dbg_report(f"conv dgrad Cin={Cin} Cout={Cout} rows {spec.out_rows}->{spec.in_rows} flip={spec.bwd_ix.flip}", gx.double(), ref)
         if ctx.needs_input_grad[1]:
-            gwk = K.conv_wgrad(x, grad_out, spec.taps, spec.fwd_ix, nbr_keepalive=spec.fwd_nbr)             # kernel layout
+            if PRESPLIT and K.get_conv_math() == "bf16x3" and Cout >= 64 and Cin >= 64 and Cout % 4 == 0:
+                xs = ctx.xs if ctx.xs is not None else (split_activation(x) if spec.fwd_ix.mode != 3 else None)
+                gwk = K.conv_wgrad(xs if xs is not None else x, split_activation(grad_out), spec.taps, spec.fwd_ix, nbr_keepalive=spec.fwd_nbr,
+                                   in_split=xs is not None, go_split=True)
+            else:
+                gwk = K.conv_wgrad(x, grad_out, spec.taps, spec.fwd_ix, nbr_keepalive=spec.fwd_nbr)         # kernel layout
             if spec.param_kind == 0:
                 gw = gwk.reshape(weight.shape)
             elif spec.param_kind == 1:
@@ -247,7 +306,12 @@ def conv(x, weight, bias, spec, Cout, stats=None):
 
 def conv_inference(x, weight, bias, spec, Cout, scale=None, shift=None, residual=None, relu=False):
     """Frozen path (teacher): conv + folded eval-mode BatchNorm + residual + ReLU in ONE kernel, no graph."""
-    wk = kernel_weight(weight, Cout, x.shape[1], spec.taps, spec.param_kind)
+    Cin = x.shape[1]
+    wk = kernel_weight(weight, Cout, Cin, spec.taps, spec.param_kind)
+    if _b3_presplit(Cin, Cout, spec.fwd_ix.mode):
+        return K.conv_fwd(split_activation(x), kernel_weight_split(weight, wk, Cout, Cin, spec.taps), spec.taps, bias, spec.out_rows, Cout,
+                          spec.fwd_ix, scale=scale, shift=shift, residual=residual, relu=relu, nbr_keepalive=spec.fwd_nbr,
+                          in_split=True, w_split=True)
     return K.conv_fwd(x, wk, spec.taps, bias, spec.out_rows, Cout, spec.fwd_ix, scale=scale, shift=shift, residual=residual,
                       relu=relu, nbr_keepalive=spec.fwd_nbr)
 

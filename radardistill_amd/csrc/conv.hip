@@ -249,7 +249,7 @@ static int g_conv_math = 0;
 int launch_conv_b3(const ConvArgs &a, int mode, hipStream_t st);
 int launch_dgrad_b3(const ConvArgs &a, hipStream_t st);
 int launch_wgrad_b3(const float *in, int in_rows, int Cin, const float *go, int out_rows, int Cout, int taps, const rd_conv_index *idx, float *gw,
-                    int rows_per_block, int64_t chunks, int tiles, int cin_tile, hipStream_t st);
+                    int rows_per_block, int64_t chunks, int tiles, int cin_tile, int in_split, int go_split, hipStream_t st);
 extern "C" int rd_set_conv_math(int mode) {
     RD_REQUIRE(mode == 0 || mode == 1, "rd_set_conv_math: mode must be 0 (f32) or 1 (bf16x3)");
     g_conv_math = mode;
@@ -257,15 +257,38 @@ extern "C" int rd_set_conv_math(int mode) {
 }
 extern "C" int rd_get_conv_math(void) { return g_conv_math; }
 
+static int conv_fwd_impl(const float *in, int in_rows, int Cin, const float *weight_k, int taps, const float *bias, float *out,
+                         int out_rows, int Cout, const rd_conv_index *idx, const float *scale, const float *shift,
+                         const float *residual, int relu, float *stats, int in_split, int w_split, void *stream);
+
 extern "C" int rd_conv_fwd(const float *in, int in_rows, int Cin, const float *weight_k, int taps, const float *bias, float *out,
                            int out_rows, int Cout, const rd_conv_index *idx, const float *scale, const float *shift,
                            const float *residual, int relu, float *stats, void *stream) {
+    return conv_fwd_impl(in, in_rows, Cin, weight_k, taps, bias, out, out_rows, Cout, idx, scale, shift, residual, relu, stats, 0, 0, stream);
+}
+
+// Same convolution with operands already in split format (rd_split_bf16): bf16x3 mode, Cout > 32, no deformable sampling of a
+// split input (its bilinear blend needs fp32 rows).
+extern "C" int rd_conv_fwd_split(const void *in, int in_is_split, int in_rows, int Cin, const void *weight_k, int w_is_split, int taps,
+                                 const float *bias, float *out, int out_rows, int Cout, const rd_conv_index *idx, const float *scale,
+                                 const float *shift, const float *residual, int relu, float *stats, void *stream) {
+    RD_REQUIRE(g_conv_math == 1 && Cout > 32, "rd_conv_fwd_split: needs bf16x3 mode (rd_set_conv_math(1)) and Cout > 32");
+    RD_REQUIRE(!(idx && idx->mode == 3 && in_is_split), "rd_conv_fwd_split: a deformable conv blends fp32 input rows (pass the input unsplit)");
+    return conv_fwd_impl(reinterpret_cast<const float *>(in), in_rows, Cin, reinterpret_cast<const float *>(weight_k), taps, bias, out, out_rows,
+                         Cout, idx, scale, shift, residual, relu, stats, in_is_split ? 1 : 0, w_is_split ? 1 : 0, stream);
+}
+
+static int conv_fwd_impl(const float *in, int in_rows, int Cin, const float *weight_k, int taps, const float *bias, float *out,
+                         int out_rows, int Cout, const rd_conv_index *idx, const float *scale, const float *shift,
+                         const float *residual, int relu, float *stats, int in_split, int w_split, void *stream) {
     RD_REQUIRE(Cin > 0 && Cin % KB == 0, "rd_conv_fwd: Cin=%d must be a multiple of %d", Cin, KB);
     RD_REQUIRE(Cout > 0 && in_rows >= 0 && out_rows >= 0, "rd_conv_fwd: bad sizes");
     int rc = validate_index(idx, taps, in_rows, out_rows, "rd_conv_fwd");
     if (rc) return rc;
     if (out_rows == 0) return RD_OK;
     ConvArgs a{in, in_rows, Cin, weight_k, taps, bias, out, out_rows, Cout, *idx, scale, shift, residual, relu, stats};
+    a.in_split = in_split;
+    a.w_split = w_split;
     hipStream_t st = S(stream);
     dim3 block(256);
     if (g_conv_math == 1 && Cout > 32) {
@@ -542,8 +565,25 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const WgradArgs a) {
     }
 }
 
+static int conv_wgrad_impl(const float *in, int in_rows, int Cin, const float *grad_out, int out_rows, int Cout, int taps,
+                           const rd_conv_index *idx, float *grad_wk, int in_split, int go_split, void *stream);
+
 extern "C" int rd_conv_wgrad(const float *in, int in_rows, int Cin, const float *grad_out, int out_rows, int Cout, int taps,
                              const rd_conv_index *idx, float *grad_wk, void *stream) {
+    return conv_wgrad_impl(in, in_rows, Cin, grad_out, out_rows, Cout, taps, idx, grad_wk, 0, 0, stream);
+}
+
+// Weight gradient with operands already in split format (bf16x3 mode, Cout >= 64, Cin >= 64, Cout % 4 == 0).
+extern "C" int rd_conv_wgrad_split(const void *in, int in_is_split, int in_rows, int Cin, const void *grad_out, int go_is_split, int out_rows,
+                                   int Cout, int taps, const rd_conv_index *idx, float *grad_wk, void *stream) {
+    RD_REQUIRE(g_conv_math == 1 && Cout >= 64 && Cin >= 64 && Cout % 4 == 0, "rd_conv_wgrad_split: needs bf16x3 mode, Cout >= 64 (multiple of 4), Cin >= 64");
+    RD_REQUIRE(!(idx && idx->mode == 3 && in_is_split), "rd_conv_wgrad_split: a deformable conv blends fp32 input rows (pass the input unsplit)");
+    return conv_wgrad_impl(reinterpret_cast<const float *>(in), in_rows, Cin, reinterpret_cast<const float *>(grad_out), out_rows, Cout, taps, idx,
+                           grad_wk, in_is_split ? 1 : 0, go_is_split ? 1 : 0, stream);
+}
+
+static int conv_wgrad_impl(const float *in, int in_rows, int Cin, const float *grad_out, int out_rows, int Cout, int taps,
+                           const rd_conv_index *idx, float *grad_wk, int in_split, int go_split, void *stream) {
     RD_REQUIRE(Cin > 0 && Cin % 32 == 0, "rd_conv_wgrad: Cin=%d must be a multiple of 32", Cin);
     RD_REQUIRE(Cout > 0, "rd_conv_wgrad: bad Cout");
     int rc = validate_index(idx, taps, in_rows, out_rows, "rd_conv_wgrad");
@@ -577,7 +617,7 @@ extern "C" int rd_conv_wgrad(const float *in, int in_rows, int Cin, const float 
     chunks = cdiv(out_rows, rows_per_block);
     hipStream_t st = S(stream);
     if (b3) {
-        launch_wgrad_b3(in, in_rows, Cin, grad_out, out_rows, Cout, taps, idx, grad_wk, rows_per_block, chunks, tiles, bn, st);
+        launch_wgrad_b3(in, in_rows, Cin, grad_out, out_rows, Cout, taps, idx, grad_wk, rows_per_block, chunks, tiles, bn, in_split, go_split, st);
         return check_launch("rd_conv_wgrad(bf16x3)");
     }
     WgradArgs a{in, in_rows, Cin, grad_out, out_rows, Cout, taps, *idx, grad_wk, rows_per_block};
@@ -592,39 +632,69 @@ extern "C" int rd_conv_wgrad(const float *in, int in_rows, int Cin, const float 
     return check_launch("rd_conv_wgrad");
 }
 
-__global__ void k_weight_layout(const float *src, float *dst, int Cout, int Cin, int taps, int kind, int flip) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t total = (int64_t)Cout * Cin * taps;
-    if (i >= total) return;
-    // i indexes the DESTINATION linearly
+// source index of destination element i (i enumerates the DESTINATION linearly) for every layout kind
+__device__ __forceinline__ int64_t layout_src(int64_t i, int Cout, int Cin, int taps, int kind, int flip) {
     if (kind == 0) {  // [Cout][taps][Cin] -> same, optional tap flip
         int c = (int)(i % Cin), t = (int)((i / Cin) % taps), n = (int)(i / ((int64_t)Cin * taps));
         int ts = flip ? taps - 1 - t : t;
-        dst[i] = src[((int64_t)n * taps + ts) * Cin + c];
+        return ((int64_t)n * taps + ts) * Cin + c;
     } else if (kind == 1) {  // torch conv [Cout][Cin][taps] -> [Cout][taps][Cin]
         int c = (int)(i % Cin), t = (int)((i / Cin) % taps), n = (int)(i / ((int64_t)Cin * taps));
         int ts = flip ? taps - 1 - t : t;
-        dst[i] = src[((int64_t)n * Cin + c) * taps + ts];
+        return ((int64_t)n * Cin + c) * taps + ts;
     } else if (kind == 2) {  // kernel layout [Cout][taps][Cin] -> [Cin][taps][Cout]
         int n = (int)(i % Cout), t = (int)((i / Cout) % taps), c = (int)(i / ((int64_t)Cout * taps));
         int ts = flip ? taps - 1 - t : t;
-        dst[i] = src[((int64_t)n * taps + ts) * Cin + c];
+        return ((int64_t)n * taps + ts) * Cin + c;
     } else if (kind == 3) {  // torch ConvTranspose2d [Cin][Cout][taps] -> [Cout][taps][Cin]
         int c = (int)(i % Cin), t = (int)((i / Cin) % taps), n = (int)(i / ((int64_t)Cin * taps));
         int ts = flip ? taps - 1 - t : t;
-        dst[i] = src[((int64_t)c * Cout + n) * taps + ts];
+        return ((int64_t)c * Cout + n) * taps + ts;
     } else if (kind == 4) {  // [Cout][taps][Cin] -> torch conv [Cout][Cin][taps]
         int t = (int)(i % taps), c = (int)((i / taps) % Cin), n = (int)(i / ((int64_t)Cin * taps));
         int ts = flip ? taps - 1 - t : t;
-        dst[i] = src[((int64_t)n * taps + ts) * Cin + c];
+        return ((int64_t)n * taps + ts) * Cin + c;
     } else if (kind == 6) {  // kernel layout [Cout][taps][Cin] -> [taps][Cin][Cout]  (DCN column-gradient operand)
         int n = (int)(i % Cout), c = (int)((i / Cout) % Cin), t = (int)(i / ((int64_t)Cout * Cin));
-        dst[i] = src[((int64_t)n * taps + t) * Cin + c];
-    } else if (kind == 5) {  // [Cout][taps][Cin] -> torch ConvTranspose2d [Cin][Cout][taps]
+        return ((int64_t)n * taps + t) * Cin + c;
+    } else {  // kind 5: [Cout][taps][Cin] -> torch ConvTranspose2d [Cin][Cout][taps]
         int t = (int)(i % taps), n = (int)((i / taps) % Cout), c = (int)(i / ((int64_t)Cout * taps));
         int ts = flip ? taps - 1 - t : t;
-        dst[i] = src[((int64_t)n * taps + ts) * Cin + c];
+        return ((int64_t)n * taps + ts) * Cin + c;
     }
+}
+
+__global__ void k_weight_layout(const float *src, float *dst, int Cout, int Cin, int taps, int kind, int flip) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Cout * Cin * taps) return;
+    dst[i] = src[layout_src(i, Cout, Cin, taps, kind, flip)];
+}
+
+// same transform, destination written in split format (rd_split_bf16): 4 consecutive destination elements per thread
+__global__ void k_weight_layout_split(const float *src, uint2 *dst_hi_lo, int Cout, int Cin, int taps, int kind, int flip) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g * 4 >= (int64_t)Cout * Cin * taps) return;
+    unsigned short hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float v = src[layout_src(g * 4 + e, Cout, Cin, taps, kind, flip)];
+        const __bf16 h = (__bf16)v;
+        const __bf16 l = (__bf16)(v - (float)h);
+        hi[e] = __builtin_bit_cast(unsigned short, h);
+        lo[e] = __builtin_bit_cast(unsigned short, l);
+    }
+    dst_hi_lo[2 * g] = make_uint2(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16));
+    dst_hi_lo[2 * g + 1] = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
+}
+
+// destination in split format: kinds whose destination's fastest axis has a multiple-of-4 extent (the K axis of the consuming GEMM)
+extern "C" int rd_weight_layout_split(const float *src, void *dst, int Cout, int Cin, int taps, int kind, int flip, void *stream) {
+    RD_REQUIRE(kind >= 0 && kind <= 3, "rd_weight_layout_split: kinds 0..3 (operand layouts) only, got %d", kind);
+    RD_REQUIRE((kind == 2 ? Cout : Cin) % 4 == 0, "rd_weight_layout_split: the destination's fastest axis must be a multiple of 4");
+    int64_t total = (int64_t)Cout * Cin * taps;
+    if (total <= 0) return RD_OK;
+    k_weight_layout_split<<<cdiv(total / 4, 256), 256, 0, S(stream)>>>(src, reinterpret_cast<uint2 *>(dst), Cout, Cin, taps, kind, flip);
+    return check_launch("rd_weight_layout_split");
 }
 
 extern "C" int rd_weight_layout(const float *src, float *dst, int Cout, int Cin, int taps, int kind, int flip, void *stream) {

@@ -11,6 +11,7 @@
 // Tile: BM x BN output, K step 32 input channels of one tap (two k16 MFMA steps), 4 waves (2 x 2).  LDS image per operand and
 // part: [rows][32] bf16, 16-byte chunks XOR-swizzled by the row (a 16-lane ds_read_b128 group covers all 64 banks once).  Lane l reads A[row l&31]
 // [k = 8*(l>>5) + 0..7] as one 16-byte fragment (the 32x32x16 bf16 operand map).
+#include <algorithm>
 #include "conv_common.hpp"
 
 using namespace rd;
@@ -28,6 +29,41 @@ __device__ __forceinline__ void split4(const f32x4 v, bf16x4 &hi, bf16x4 &lo) {
         hi[e] = h;
         lo[e] = (__bf16)(v[e] - (float)h);
     }
+}
+
+// 16-byte split-format group -> its hi and lo halves
+__device__ __forceinline__ void unpack4(const f32x4 v, bf16x4 &hi, bf16x4 &lo) {
+    union {
+        f32x4 f;
+        bf16x4 h[2];
+    } u;
+    u.f = v;
+    hi = u.h[0];
+    lo = u.h[1];
+}
+
+// fp32 -> split format, elementwise (n4 groups of 4): the producer-side half of the pre-split operand path
+__global__ void k_split_bf16(const f32x4 *__restrict__ x, int64_t n4, f32x4 *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        bf16x4 hi, lo;
+        split4(x[i], hi, lo);
+        union {
+            f32x4 f;
+            bf16x4 h[2];
+        } u;
+        u.h[0] = hi;
+        u.h[1] = lo;
+        out[i] = u.f;
+    }
+}
+
+extern "C" int rd_split_bf16(const float *x, int64_t n, void *out, void *stream) {
+    RD_REQUIRE(n >= 0 && n % 4 == 0, "rd_split_bf16: element count %lld must be a multiple of 4", (long long)n);
+    if (n == 0) return RD_OK;
+    const int64_t n4 = n / 4;
+    k_split_bf16<<<(unsigned)std::min<int64_t>(cdiv(n4, 256), 4096), 256, 0, S(stream)>>>(reinterpret_cast<const f32x4 *>(x), n4,
+                                                                                         reinterpret_cast<f32x4 *>(out));
+    return check_launch("rd_split_bf16");
 }
 
 // BT = true: data gradient on the forward weights, B[k][n] = w[k][tap][n] (see k_conv_igemm in conv.hip).  The weight tile then
@@ -149,7 +185,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
             bf16x4 hi, lo;
-            split4(ra[p], hi, lo);
+            if (!DEFORM && a.in_split) unpack4(ra[p], hi, lo);     // block-uniform
+            else split4(ra[p], hi, lo);
             *reinterpret_cast<bf16x4 *>(Ah + off(ld_r + 32 * p)) = hi;
             *reinterpret_cast<bf16x4 *>(Al + off(ld_r + 32 * p)) = lo;
         }
@@ -170,7 +207,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
 #pragma unroll
             for (int p = 0; p < BP; ++p) {
                 bf16x4 hi, lo;
-                split4(rb[p], hi, lo);
+                if (a.w_split) unpack4(rb[p], hi, lo);
+                else split4(rb[p], hi, lo);
                 *reinterpret_cast<bf16x4 *>(Bh + off(ld_r + 32 * p)) = hi;
                 *reinterpret_cast<bf16x4 *>(Bl + off(ld_r + 32 * p)) = lo;
             }
@@ -307,6 +345,7 @@ struct WgradArgsB3 {
     rd_conv_index ix;
     float *gw;
     int rows_per_block;
+    int in_split, go_split;   // operands already in split format (rd_split_bf16)
 };
 
 // TN = Cin tile (128, or 64 for Cin <= 64 layers such as the batched CenterHead first conv); the Cout tile is always 128.
@@ -420,16 +459,29 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_b3(const WgradArgsB3 a) {
         if (dense) advance(cb, cy, cx, KB3);
     };
     // 4x4 register transpose + hi/lo split: element (row e, channel c) -> piece of channel c holding rows 0..3
-    auto store_block = [&](const f32x4 (&blk)[4], __bf16 *hi_img, __bf16 *lo_img) {
+    auto store_block = [&](const f32x4 (&blk)[4], __bf16 *hi_img, __bf16 *lo_img, int presplit) {
+        bf16x4 ph[4], pl[4];
+        if (presplit) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) unpack4(blk[e], ph[e], pl[e]);
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             bf16x4 hi, lo;
+            if (presplit) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v = blk[e][c];
-                const __bf16 h = (__bf16)v;
-                hi[e] = h;
-                lo[e] = (__bf16)(v - (float)h);
+                for (int e = 0; e < 4; ++e) {
+                    hi[e] = ph[e][c];
+                    lo[e] = pl[e][c];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = blk[e][c];
+                    const __bf16 h = (__bf16)v;
+                    hi[e] = h;
+                    lo[e] = (__bf16)(v - (float)h);
+                }
             }
             *reinterpret_cast<bf16x4 *>(hi_img + (4 * q + c) * LDB + 4 * g) = hi;
             *reinterpret_cast<bf16x4 *>(lo_img + (4 * q + c) * LDB + 4 * g) = lo;
@@ -441,8 +493,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_b3(const WgradArgsB3 a) {
     const int fr = lane & 31, fh = lane >> 5;
     for (int s = 0; s < n_steps; ++s) {
         __syncthreads();                          // previous step's fragment reads are done
-        store_block(rg, Gh, Gl);
-        if (4 * q < TN) store_block(rx, Xh, Xl);
+        store_block(rg, Gh, Gl, a.go_split);
+        if (4 * q < TN) store_block(rx, Xh, Xl, DEFORM ? 0 : a.in_split);
         if (any_next) s_any = s + 1;              // tag = step index + 1: no reset pass needed
         __syncthreads();
         const bool any = s_any == s + 1;
@@ -491,8 +543,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_b3(const WgradArgsB3 a) {
 }
 
 int launch_wgrad_b3(const float *in, int in_rows, int Cin, const float *go, int out_rows, int Cout, int taps, const rd_conv_index *idx, float *gw,
-                    int rows_per_block, int64_t chunks, int tiles, int cin_tile, hipStream_t st) {
-    WgradArgsB3 a{in, in_rows, Cin, go, out_rows, Cout, taps, *idx, gw, rows_per_block};
+                    int rows_per_block, int64_t chunks, int tiles, int cin_tile, int in_split, int go_split, hipStream_t st) {
+    WgradArgsB3 a{in, in_rows, Cin, go, out_rows, Cout, taps, *idx, gw, rows_per_block, in_split, go_split};
     dim3 grid((unsigned)chunks, (unsigned)tiles);
     if (cin_tile == 128) {
         if (idx->mode == 3) k_conv_wgrad_b3<true, 128><<<grid, 256, 0, st>>>(a);

@@ -21,6 +21,9 @@ struct ConvArgs {
     const float *scale, *shift, *residual;
     int relu;
     float *stats;
+    // bf16x3 kernels only: operand already in "split format" (rd_split_bf16): every 16-byte group of 4 channels holds
+    // [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] as bf16 instead of 4 floats -- same size, same addressing, no in-loop split
+    int in_split = 0, w_split = 0;
 };
 
 __device__ __forceinline__ int src_row(const ConvArgs &a, int j, int t) {

@@ -159,8 +159,30 @@ def conv_index_dense(B, Hin, Win, Hout, Wout, KH, KW, stride, pad, transposed=Fa
 CONV_PROFILE = None
 
 
-def conv_fwd(x, weight_k, taps, bias, out_rows, Cout, ix, scale=None, shift=None, residual=None, relu=False, stats=None, nbr_keepalive=None):
-    """x (in_rows, Cin); weight_k (Cout, taps, Cin) kernel layout -> (out_rows, Cout)."""
+def split_bf16(x):
+    """fp32 tensor -> the same bytes in split format ([4 x bf16 hi | 4 x bf16 lo] per 4 elements; kept in an fp32-typed tensor)."""
+    _chk(x, f32, "split input")
+    if x.numel() % 4:
+        raise RuntimeError("split_bf16: element count must be a multiple of 4")
+    out = torch.empty_like(x)
+    check(native.lib().rd_split_bf16(_p(x), x.numel(), _p(out), _stream()), "rd_split_bf16")
+    return out
+
+
+def weight_layout_split(src, Cout, Cin, taps, kind, flip=False):
+    """Like weight_layout (kinds 0..3) with the destination written in split format."""
+    _chk(src, f32, "weight")
+    if src.numel() != Cout * Cin * taps:
+        raise RuntimeError("weight_layout_split: element count mismatch")
+    dst = torch.empty(Cout * Cin * taps, dtype=f32, device=src.device)
+    check(native.lib().rd_weight_layout_split(_p(src), _p(dst), Cout, Cin, taps, kind, int(flip), _stream()), "rd_weight_layout_split")
+    return dst
+
+
+def conv_fwd(x, weight_k, taps, bias, out_rows, Cout, ix, scale=None, shift=None, residual=None, relu=False, stats=None, nbr_keepalive=None,
+             in_split=False, w_split=False):
+    """x (in_rows, Cin); weight_k (Cout, taps, Cin) kernel layout -> (out_rows, Cout).  in_split / w_split: that operand is already in
+    split format (bf16x3 mode)."""
     _chk(x, f32, "conv input", 2)
     _chk(weight_k, f32, "conv weight")
     in_rows, Cin = x.shape
@@ -181,8 +203,13 @@ def conv_fwd(x, weight_k, taps, bias, out_rows, Cout, ix, scale=None, shift=None
     if prof:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(native.lib().rd_conv_fwd(_p(x), in_rows, Cin, _p(weight_k), taps, _p(bias), _p(out), out_rows, Cout, ctypes.byref(ix),
-                                   _p(scale), _p(shift), _p(residual), int(relu), _p(stats), _stream()), "rd_conv_fwd")
+    if in_split or w_split:
+        check(native.lib().rd_conv_fwd_split(_p(x), int(in_split), in_rows, Cin, _p(weight_k), int(w_split), taps, _p(bias), _p(out), out_rows, Cout,
+                                             ctypes.byref(ix), _p(scale), _p(shift), _p(residual), int(relu), _p(stats), _stream()),
+              "rd_conv_fwd_split")
+    else:
+        check(native.lib().rd_conv_fwd(_p(x), in_rows, Cin, _p(weight_k), taps, _p(bias), _p(out), out_rows, Cout, ctypes.byref(ix),
+                                       _p(scale), _p(shift), _p(residual), int(relu), _p(stats), _stream()), "rd_conv_fwd")
     if prof:
         e1.record()
         # algorithmic flops: dense 2*k^2*Cin*Cout*rows_out; sparse 2*pairs*Cin*Cout (pairs = valid table entries,
@@ -233,8 +260,8 @@ def conv_dgrad(grad_out, weight_k, taps, in_rows, Cin, ix_bwd, nbr_keepalive=Non
 WGRAD_PROFILE = None
 
 
-def conv_wgrad(x, grad_out, taps, ix, nbr_keepalive=None):
-    """-> grad weight in kernel layout (Cout, taps, Cin)."""
+def conv_wgrad(x, grad_out, taps, ix, nbr_keepalive=None, in_split=False, go_split=False):
+    """-> grad weight in kernel layout (Cout, taps, Cin).  in_split / go_split: operand already in split format (bf16x3 mode)."""
     _chk(x, f32, "wgrad input", 2)
     _chk(grad_out, f32, "wgrad grad_out", 2)
     in_rows, Cin = x.shape
@@ -245,8 +272,12 @@ def conv_wgrad(x, grad_out, taps, ix, nbr_keepalive=None):
     if prof:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(native.lib().rd_conv_wgrad(_p(x), in_rows, Cin, _p(grad_out), out_rows, Cout, taps, ctypes.byref(ix), _p(gw), _stream()),
-          "rd_conv_wgrad")
+    if in_split or go_split:
+        check(native.lib().rd_conv_wgrad_split(_p(x), int(in_split), in_rows, Cin, _p(grad_out), int(go_split), out_rows, Cout, taps,
+                                               ctypes.byref(ix), _p(gw), _stream()), "rd_conv_wgrad_split")
+    else:
+        check(native.lib().rd_conv_wgrad(_p(x), in_rows, Cin, _p(grad_out), out_rows, Cout, taps, ctypes.byref(ix), _p(gw), _stream()),
+              "rd_conv_wgrad")
     if prof:
         e1.record()
         pairs = None

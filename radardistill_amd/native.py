@@ -53,6 +53,10 @@ SIGNATURES = {
     "rd_conv_fwd": (c_int, [_P, c_int, c_int, _P, c_int, _P, _P, c_int, c_int, ctypes.POINTER(ConvIndex), _P, _P, _P, c_int, _P, _P]),
     "rd_set_conv_math": (c_int, [c_int]),
     "rd_get_conv_math": (c_int, []),
+    "rd_split_bf16": (c_int, [_P, c_i64, _P, _P]),
+    "rd_weight_layout_split": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "rd_conv_fwd_split": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, c_int, c_int, ctypes.POINTER(ConvIndex), _P, _P, _P, c_int, _P, _P]),
+    "rd_conv_wgrad_split": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, ctypes.POINTER(ConvIndex), _P, _P]),
     "rd_conv_dgrad": (c_int, [_P, c_int, c_int, _P, c_int, _P, c_int, c_int, ctypes.POINTER(ConvIndex), _P]),
     "rd_conv_wgrad": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, ctypes.POINTER(ConvIndex), _P, _P]),
     "rd_weight_layout": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),

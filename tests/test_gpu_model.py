@@ -502,3 +502,32 @@ def test_pillarnet_eval_forward_and_recall():
         for k in want:
             want[k] += rec[k]
     assert {k: recall[k] for k in want} == want
+
+
+def test_split_format_round_trip_and_presplit_conv():
+    """rd_split_bf16: hi + lo reproduces x to ~2^-17; a conv on pre-split operands equals the in-loop split bit for bit."""
+    from radardistill_amd import autograd as A, kernels as K
+    g = np.random.default_rng(3)
+    x = torch.from_numpy(g.normal(size=(1000, 64)).astype(np.float32) * 7).to(DEV)
+    xs = K.split_bf16(x)
+    raw = xs.view(torch.bfloat16).view(-1, 8).float()                 # [hi0..hi3 | lo0..lo3] per group of 4
+    rec = (raw[:, :4] + raw[:, 4:]).reshape(x.shape)
+    assert float(((rec - x).abs() / x.abs().clamp_min(1e-20)).max()) < 2 ** -15
+    assert torch.equal(raw[:, :4].reshape(x.shape), x.to(torch.bfloat16).float())
+    K.set_conv_math("bf16x3")
+    try:
+        spec = A.dense_conv_spec(2, 16, 16, 3, 3, 1, 1)
+        xi = torch.from_numpy(g.normal(size=(512, 64)).astype(np.float32)).to(DEV)
+        w = torch.from_numpy(g.normal(size=(96, 9, 64)).astype(np.float32) * 0.1).to(DEV)
+        ref = K.conv_fwd(xi, w, 9, None, 512, 96, spec.fwd_ix)
+        ws = K.weight_layout_split(w, 96, 64, 9, 0)
+        for a_s, b_s in ((True, True), (True, False), (False, True)):
+            out = K.conv_fwd(K.split_bf16(xi) if a_s else xi, ws if b_s else w, 9, None, 512, 96, spec.fwd_ix, in_split=a_s, w_split=b_s)
+            assert torch.equal(out, ref), (a_s, b_s)
+        go = torch.from_numpy(g.normal(size=(512, 96)).astype(np.float32)).to(DEV)
+        A.begin_step(torch.device(DEV))
+        gw_ref = K.conv_wgrad(xi, go, 9, spec.fwd_ix).clone()
+        gw = K.conv_wgrad(K.split_bf16(xi), K.split_bf16(go), 9, spec.fwd_ix, in_split=True, go_split=True)
+        close(gw, gw_ref, rtol=1e-5, atol=1e-6)                        # same products, atomics in another order
+    finally:
+        K.set_conv_math("f32")
