@@ -350,6 +350,17 @@ int rd_pillar_vfe_max(const float *voxels, const int32_t *num_points, const int3
                       int Cin, int Cout, int use_abs_xyz, int with_distance, float vx, float vy, float vz, float xoff, float yoff,
                       float zoff, const float *scale, const float *shift, float *out, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * O. GELU + Global Response Normalisation of the ConvNeXt-V2 MLP (pcdet/ops/basicblock/modules/Basicblock_convn.py:46-60,83-85):
+ *    z (B*hw, C) rows of B samples -> a = gelu(z) (saved), ssq (B, C) = per-sample column sums of a^2 (saved),
+ *    out = gamma * (a * N) + beta + a with N = G / (mean_c G + 1e-6), G = sqrt(ssq).  Backward: grad_z, grad_gamma, grad_beta
+ *    (S_ws: B*C floats of scratch).  All buffers are zero-filled inside where they accumulate.
+ * ---------------------------------------------------------------------------------------------- */
+int rd_gelu_grn_fwd(const float *z, int B, int64_t hw, int C, const float *gamma, const float *beta, float *a, float *ssq, float *out,
+                    void *stream);
+int rd_gelu_grn_bwd(const float *grad_out, const float *a, const float *z, const float *ssq, int B, int64_t hw, int C, const float *gamma,
+                    float *S_ws, float *grad_z, float *grad_gamma, float *grad_beta, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -502,3 +502,27 @@ def nconv(y, weight, bias, B, H, W, tab):
     if torch.is_grad_enabled() and (y.requires_grad or weight.requires_grad):
         return _NConvFn.apply(y, weight, bias, B, H, W, tab)
     return K.nconv_fwd(y, weight.detach().contiguous(), bias.detach().contiguous() if bias is not None else None, B, H, W, tab)
+
+
+class _GeluGRNFn(torch.autograd.Function):
+    """gelu followed by Global Response Normalisation over each sample's rows (convnext.hip)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, B):
+        g1, b1 = gamma.detach().reshape(-1).contiguous(), beta.detach().reshape(-1).contiguous()
+        out, a, ssq = K.gelu_grn_fwd(z, B, g1, b1)
+        ctx.B = B
+        ctx.shapes = (gamma.shape, beta.shape)
+        ctx.save_for_backward(z, a, ssq, g1)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        z, a, ssq, g1 = ctx.saved_tensors
+        gz, gg, gb = K.gelu_grn_bwd(go.contiguous(), a, z, ssq, ctx.B, g1)
+        return gz, gg.reshape(ctx.shapes[0]), gb.reshape(ctx.shapes[1]), None
+
+
+def gelu_grn(z_rows, grn, B):
+    """act = GELU then grn (Basicblock_convn.GRN parameter container) on rows (B*hw, C)."""
+    return _GeluGRNFn.apply(z_rows, grn.gamma, grn.beta, B)

@@ -597,6 +597,30 @@ def nconv_wgrad(y, grad_out, B, H, W, tab):
     return gw
 
 
+# ------------------------------------------------------------------------------------------ ConvNeXt MLP tail
+def gelu_grn_fwd(z, B, gamma, beta):
+    """z (B*hw, C) -> (out, a = gelu(z), ssq (B, C)): GELU + GRN in two passes."""
+    _chk(z, f32, "gelu_grn input", 2)
+    rows, C = z.shape
+    if rows % B or _chk(gamma, f32, "gamma").numel() != C or _chk(beta, f32, "beta").numel() != C:
+        raise RuntimeError("gelu_grn_fwd: shape mismatch")
+    a = torch.empty_like(z); out = torch.empty_like(z)
+    ssq = torch.empty((B, C), dtype=f32, device=z.device)
+    check(native.lib().rd_gelu_grn_fwd(_p(z), B, rows // B, C, _p(gamma), _p(beta), _p(a), _p(ssq), _p(out), _stream()), "rd_gelu_grn_fwd")
+    return out, a, ssq
+
+
+def gelu_grn_bwd(grad_out, a, z, ssq, B, gamma):
+    _chk(grad_out, f32, "gelu_grn grad_out", 2)
+    rows, C = grad_out.shape
+    gz = torch.empty_like(z)
+    gg = torch.empty(C, dtype=f32, device=z.device); gb = torch.empty(C, dtype=f32, device=z.device)
+    ws = torch.empty((B, C), dtype=f32, device=z.device)
+    check(native.lib().rd_gelu_grn_bwd(_p(grad_out), _p(a), _p(z), _p(ssq), B, rows // B, C, _p(gamma), _p(ws), _p(gz), _p(gg), _p(gb), _stream()),
+          "rd_gelu_grn_bwd")
+    return gz, gg, gb
+
+
 # ------------------------------------------------------------------------------------------ padded-voxel input format
 def voxelize_hard(points, batch, grid_xyz, pc_range, voxel_size, max_points, max_voxels):
     """points (N, 1+C) [batch id, x, y, z, ...] sorted by batch id -> (voxels (M, max_points, C), coords (M, 4) int32 (b, z, y, x),

@@ -75,7 +75,9 @@ class ConvNeXtBlock(nn.Module):
         y = A.dwconv(rows, self.dwconv, B, H, W)                                             # depthwise 7x7 (dwconv.hip)
         y = self.norm(y.view(B, H, W, C))
         y = D.linear_rows(y.reshape(-1, C), self.pwconv1)
-        y = self.act(y)
-        y = self.grn(y.view(B, H, W, 4 * C))
+        if y.is_cuda and isinstance(self.act, nn.GELU) and getattr(self.act, 'approximate', 'none') == 'none':
+            y = A.gelu_grn(y, self.grn, B)                                                   # GELU + GRN fused (convnext.hip)
+        else:
+            y = self.grn(self.act(y).view(B, H, W, 4 * C)).reshape(-1, 4 * C)
         y = D.linear_rows(y.reshape(-1, 4 * C), self.pwconv2)
         return A.rows_to_nchw(y + identity, B, H, W)

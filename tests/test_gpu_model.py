@@ -531,3 +531,30 @@ def test_split_format_round_trip_and_presplit_conv():
         close(gw, gw_ref, rtol=1e-5, atol=1e-6)                        # same products, atomics in another order
     finally:
         K.set_conv_math("f32")
+
+
+@pytest.mark.parametrize("B,hw,C", [(2, 256, 1024), (3, 37, 64), (1, 1000, 260)])
+def test_fused_gelu_grn_forward_backward(B, hw, C):
+    """rd_gelu_grn_{fwd,bwd} vs nn.GELU + GRN (Basicblock_convn.py:46-60) under torch autograd on the CPU."""
+    from radardistill_amd import autograd as A
+    from radardistill_amd.pcdet.ops.basicblock.Basicblock_convn import GRN
+    g = np.random.default_rng(B * 7 + C)
+    z = torch.from_numpy(g.normal(size=(B, hw, 1, C)).astype(np.float32))
+    go = torch.from_numpy(g.normal(size=(B, hw, 1, C)).astype(np.float32))
+    grn = GRN(C)
+    with torch.no_grad():
+        grn.gamma.copy_(torch.from_numpy(g.normal(size=(1, 1, 1, C)).astype(np.float32)))
+        grn.beta.copy_(torch.from_numpy(g.normal(size=(1, 1, 1, C)).astype(np.float32)))
+    zr = z.clone().requires_grad_(True)
+    ref = grn(torch.nn.functional.gelu(zr))
+    (ref * go).sum().backward()
+    import copy
+    gd = copy.deepcopy(grn).to(DEV)
+    gd.gamma.grad = gd.beta.grad = None
+    zd = z.reshape(B * hw, C).to(DEV).requires_grad_(True)
+    out = A.gelu_grn(zd, gd, B)
+    close(out, ref.reshape(B * hw, C), rtol=1e-4, atol=1e-5, what="gelu+grn forward")
+    (out * go.reshape(B * hw, C).to(DEV)).sum().backward()
+    close(zd.grad, zr.grad.reshape(B * hw, C), rtol=1e-3, atol=1e-4, what="grad z")
+    close(gd.gamma.grad, grn.gamma.grad, rtol=1e-3, atol=1e-4, what="grad gamma")
+    close(gd.beta.grad, grn.beta.grad, rtol=1e-3, atol=1e-4, what="grad beta")
