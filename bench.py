@@ -127,7 +127,7 @@ def main():
     optimizer = build_optimizer(model, cfg.OPTIMIZATION)
     total_steps = args.steps + args.warmup
     sched, _ = build_scheduler(optimizer, max(total_steps, 10), 1, -1, cfg.OPTIMIZATION)
-    run_model = D.wrap_ddp(model, dev_index)
+    run_model = D.data_parallel(model, optimizer, dev_index)       # flat-buffer gradient all-reduce (RD_DDP=torch: DistributedDataParallel)
     model_func = model_fn_decorator()
     # a few distinct batches per rank, resident in HBM before timing; sample sharding: seed depends on the rank
     batches = [device_batch(make_batch(batch_size=args.batch, n_lidar=35000, n_radar=2000, n_boxes=30, grid=args.grid,
@@ -238,7 +238,7 @@ def main():
             "config": {"workload": "RadarDistill full training step (BASELINE configs[3]): frozen LiDAR teacher fwd + radar student "
                                    "fwd/bwd (VFE, SparseEnc, CMA+DCNv2, DenseEnc, CenterHead, AFD+PFD+detection losses) + clip + Adam",
                        "bev": f"{args.grid}x{args.grid}", "pillar_m": 0.2, "lidar_pts": 35000, "radar_pts": 2000, "boxes": 30,
-                       "conv_math": args.math, "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "conv_math": args.math, "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}" + ("" if world == 1 else ("/ddp" if os.environ.get("RD_DDP", "flat") == "torch" else "/flat-allreduce")),
                        "teacher_head": "computed (unused by the loss, as in the reference)", "final_loss": last_loss},
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",

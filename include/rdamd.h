@@ -257,12 +257,16 @@ typedef struct {
 } rd_opt_tensor;
 int rd_opt_chunk_elems(void);   /* elements per chunk of the chunk table */
 /* tensors_dev: device array of rd_opt_tensor; chunks_dev: device array of (tensor id, element offset) int32 pairs.
- * out2[0] = total 2-norm, out2[1] = clip coefficient min(1, max_norm / (norm + 1e-6)). */
+ * out2[0] = total 2-norm, out2[1] = clip coefficient min(1, max_norm / (norm + 1e-6)).
+ * Data parallelism: rd_pack_grads gathers every t.grad into ONE flat buffer laid out like the moment buffers (tensor t at element
+ * offset t.exp_avg - tensors[0].exp_avg); after the all-reduce (SUM) of that buffer, pass it as flat_grad with grad_scale =
+ * 1 / world size to the two entries below (flat_grad = NULL, grad_scale = 1: gradients are read from t.grad). */
+int rd_pack_grads(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, float *flat, void *stream);
 int rd_grad_norm(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, float max_norm, float *out2, float *ws,
-                 int64_t ws_bytes, void *stream);
+                 int64_t ws_bytes, const float *flat_grad, float grad_scale, void *stream);
 /* step = 1-based update count (bias correction).  clip_dev may be NULL (no clipping) or out2 of rd_grad_norm. */
 int rd_adam_step(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, float lr, float beta1, float beta2, float eps,
-                 float weight_decay, int step, const float *clip_dev, void *stream);
+                 float weight_decay, int step, const float *clip_dev, const float *flat_grad, float grad_scale, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * J. Depthwise KxK convolution on channels-last maps (ConvNeXt dwconv 7x7, groups = C, padding K/2).  Replaces cuDNN's

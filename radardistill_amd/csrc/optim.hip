@@ -14,16 +14,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int OPT_CHUNK = 4096;
 
 // chunk table entry: tensor id + element offset of the chunk
+// Gradients live either in per-tensor buffers (t.grad) or, after the data-parallel all-reduce, in ONE flat buffer laid out like the
+// moment buffers (element offset of tensor t = t.exp_avg - tensors[0].exp_avg), to be multiplied by grad_scale (1 / world size).
+__device__ __forceinline__ const float *grad_ptr(const rd_opt_tensor *tensors, const rd_opt_tensor &t, const float *flat) {
+    return flat ? flat + (t.exp_avg - tensors[0].exp_avg) : t.grad;
+}
+
 __global__ __launch_bounds__(256) void k_gradnorm_partial(const rd_opt_tensor *__restrict__ tensors, const int2 *__restrict__ chunks, int n_chunks,
-                                                          float *partial) {
+                                                          const float *__restrict__ flat, float grad_scale, float *partial) {
     __shared__ float red[4];
     const int2 ch = chunks[blockIdx.x];
     const rd_opt_tensor t = tensors[ch.x];
-    const float *g = t.grad + ch.y;
+    const float *g = grad_ptr(tensors, t, flat) + ch.y;
     const int64_t n = min((int64_t)OPT_CHUNK, t.numel - ch.y);
     float s = 0.f;
     for (int64_t i = threadIdx.x; i < n; i += 256) {
-        float v = g[i];
+        float v = g[i] * grad_scale;
         s += v * v;
     }
 #pragma unroll
@@ -53,14 +59,15 @@ __global__ void k_gradnorm_final(const float *partial, int n, float max_norm, fl
 }
 
 __global__ __launch_bounds__(256) void k_adam(const rd_opt_tensor *__restrict__ tensors, const int2 *__restrict__ chunks, float lr, float beta1,
-                                              float beta2, float eps, float wd, float bc1, float bc2_sqrt, const float *__restrict__ clip) {
+                                              float beta2, float eps, float wd, float bc1, float bc2_sqrt, const float *__restrict__ clip,
+                                              const float *__restrict__ flat, float grad_scale) {
     const int2 ch = chunks[blockIdx.x];
     const rd_opt_tensor t = tensors[ch.x];
     const int64_t n = min((int64_t)OPT_CHUNK, t.numel - ch.y);
     float *p = t.param + ch.y;
-    const float *g = t.grad + ch.y;
+    const float *g = grad_ptr(tensors, t, flat) + ch.y;
     float *m = t.exp_avg + ch.y, *v = t.exp_avg_sq + ch.y;
-    const float cc = clip ? clip[1] : 1.f;
+    const float cc = (clip ? clip[1] : 1.f) * grad_scale;
     const float decay = 1.f - wd * lr, step = lr / bc1;
     for (int64_t i = threadIdx.x; i < n; i += 256) {
         const float gi = g[i] * cc;
@@ -75,23 +82,41 @@ __global__ __launch_bounds__(256) void k_adam(const rd_opt_tensor *__restrict__ 
     }
 }
 
+// pack: flat[offset(t) + i] = t.grad[i] -- ONE launch gathers the ~500 gradient tensors into the buffer that is all-reduced
+__global__ __launch_bounds__(256) void k_pack_grads(const rd_opt_tensor *__restrict__ tensors, const int2 *__restrict__ chunks, float *flat) {
+    const int2 ch = chunks[blockIdx.x];
+    const rd_opt_tensor t = tensors[ch.x];
+    const int64_t n = min((int64_t)OPT_CHUNK, t.numel - ch.y);
+    const float *g = t.grad + ch.y;
+    float *d = flat + (t.exp_avg - tensors[0].exp_avg) + ch.y;
+    for (int64_t i = threadIdx.x; i < n; i += 256) d[i] = g[i];
+}
+
+extern "C" int rd_pack_grads(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, float *flat, void *stream) {
+    RD_REQUIRE(flat != nullptr, "rd_pack_grads: flat buffer is NULL");
+    if (n_chunks <= 0) return RD_OK;
+    k_pack_grads<<<n_chunks, 256, 0, S(stream)>>>(tensors_dev, reinterpret_cast<const int2 *>(chunks_dev), flat);
+    return check_launch("rd_pack_grads");
+}
+
 extern "C" int rd_grad_norm(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, float max_norm, float *out2,
-                            float *ws, int64_t ws_bytes, void *stream) {
+                            float *ws, int64_t ws_bytes, const float *flat_grad, float grad_scale, void *stream) {
     RD_REQUIRE(n_chunks >= 0 && ws_bytes >= (int64_t)n_chunks * 4, "rd_grad_norm: workspace too small");
     hipStream_t st = S(stream);
     if (n_chunks > 0)
-        k_gradnorm_partial<<<n_chunks, 256, 0, st>>>(tensors_dev, reinterpret_cast<const int2 *>(chunks_dev), n_chunks, ws);
+        k_gradnorm_partial<<<n_chunks, 256, 0, st>>>(tensors_dev, reinterpret_cast<const int2 *>(chunks_dev), n_chunks, flat_grad, grad_scale, ws);
     k_gradnorm_final<<<1, 256, 0, st>>>(ws, n_chunks, max_norm, out2);
     return check_launch("rd_grad_norm");
 }
 
 extern "C" int rd_adam_step(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, float lr, float beta1, float beta2,
-                            float eps, float weight_decay, int step, const float *clip_dev, void *stream) {
+                            float eps, float weight_decay, int step, const float *clip_dev, const float *flat_grad, float grad_scale,
+                            void *stream) {
     RD_REQUIRE(step >= 1, "rd_adam_step: step must be >= 1");
     if (n_chunks <= 0) return RD_OK;
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     k_adam<<<n_chunks, 256, 0, S(stream)>>>(tensors_dev, reinterpret_cast<const int2 *>(chunks_dev), lr, beta1, beta2, eps, weight_decay,
-                                            (float)bc1, (float)sqrt(bc2), clip_dev);
+                                            (float)bc1, (float)sqrt(bc2), clip_dev, flat_grad, grad_scale);
     return check_launch("rd_adam_step");
 }
 

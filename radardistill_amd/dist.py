@@ -40,6 +40,41 @@ def wrap_ddp(model, local_rank=None):
     return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids)
 
 
+def broadcast_parameters(model, src=0):
+    """Rank `src`'s parameters and buffers to every rank, coalesced (what DistributedDataParallel does once at construction)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    tensors = [p.data for p in model.parameters()] + [b.data for b in model.buffers()]
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for group in by_dtype.values():
+        flat = torch.cat([t.reshape(-1) for t in group])
+        dist.broadcast(flat, src)
+        off = 0
+        for t in group:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+
+
+def data_parallel(model, optimizer, device_index=None, mode=None):
+    """Set up sample-sharded data parallelism for (model, optimizer); returns the module to call in the training loop.
+
+    mode "flat" (default, RD_DDP=flat): no wrapper -- parameters are broadcast once, the fused optimizer packs all gradients into one
+    buffer, all-reduces it with a single RCCL call and consumes the averaged gradients from it (FusedAdamOneCycle
+    .enable_flat_allreduce).  BatchNorm running statistics stay local; rank 0's are what a checkpoint stores, exactly as under
+    DDP's broadcast_buffers (rank 0's buffers are never overwritten there either).
+    mode "torch" (RD_DDP=torch): torch.nn.parallel.DistributedDataParallel as in tools/train.py:174-176 of the reference."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return model
+    mode = mode or os.environ.get("RD_DDP", "flat")
+    if mode == "torch" or not hasattr(optimizer, "enable_flat_allreduce"):
+        return wrap_ddp(model, device_index)
+    broadcast_parameters(model, 0)
+    optimizer.enable_flat_allreduce()
+    return model
+
+
 def max_over_ranks(seconds, device="cpu"):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(seconds)

@@ -77,8 +77,9 @@ SIGNATURES = {
     "rd_pfd_bwd": (c_int, [_P, _P, _P, _P, c_i64, c_int, _P, _P, _P, _P, _P, _P]),
     "rd_boxes_aligned_overlap_bev": (c_int, [c_int, _P, _P, _P, _P]),
     "rd_opt_chunk_elems": (c_int, []),
-    "rd_grad_norm": (c_int, [_P, _P, c_int, c_f32, _P, _P, c_i64, _P]),
-    "rd_adam_step": (c_int, [_P, _P, c_int, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, _P, _P]),
+    "rd_pack_grads": (c_int, [_P, _P, c_int, _P, _P]),
+    "rd_grad_norm": (c_int, [_P, _P, c_int, c_f32, _P, _P, c_i64, _P, c_f32, _P]),
+    "rd_adam_step": (c_int, [_P, _P, c_int, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, _P, _P, c_f32, _P]),
     "rd_dwconv_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "rd_dwconv_wgrad_ws_bytes": (c_i64, [c_int, c_int, c_int, c_int, c_int]),
     "rd_dwconv_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_i64, _P]),

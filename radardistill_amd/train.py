@@ -87,6 +87,18 @@ class FusedAdamOneCycle:
         self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)
         self.ws = torch.empty(self.n_chunks, dtype=torch.float32, device=dev)
         self._zero = {}
+        self.flat_grad = None          # data parallelism: see enable_flat_allreduce()
+        self.process_group = None
+
+    def enable_flat_allreduce(self, process_group=None):
+        """Data-parallel gradient exchange without DistributedDataParallel: after backward ONE launch packs the ~500 gradient
+        tensors into a flat fp32 buffer (laid out like the Adam moments), ONE all-reduce (RCCL over xGMI: 100 MB, ~0.6 ms at
+        8 GPUs) sums it over the ranks, and the norm / Adam kernels read the averaged gradients straight from that buffer --
+        instead of DDP's per-parameter hooks and ~500 bucket-copy launches per step.  Parameters must start equal on all ranks
+        (dist.broadcast_parameters)."""
+        n = int(self.offsets[-1])
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
+        self.process_group = process_group
 
     def zero_grad(self):
         for p in self.params:
@@ -124,14 +136,20 @@ class FusedAdamOneCycle:
         """clip_grad_norm_(grad_clip) + OptimWrapper.step(); returns the device tensor [total_norm, clip_coef]."""
         table = self._fill_table()
         L = native.lib()
+        flat, scale = None, 1.0
+        if self.flat_grad is not None:
+            import torch.distributed as dist
+            check(L.rd_pack_grads(_p(table), _p(self.chunks_dev), self.n_chunks, _p(self.flat_grad), _stream()), "rd_pack_grads")
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.process_group)
+            flat, scale = self.flat_grad, 1.0 / dist.get_world_size(self.process_group)
         clip = None
         if self.grad_clip is not None and self.grad_clip > 0:
             check(L.rd_grad_norm(_p(table), _p(self.chunks_dev), self.n_chunks, float(self.grad_clip), _p(self.norm_out),
-                                 _p(self.ws), self.ws.numel() * 4, _stream()), "rd_grad_norm")
+                                 _p(self.ws), self.ws.numel() * 4, _p(flat), scale, _stream()), "rd_grad_norm")
             clip = self.norm_out
         self.step_count += 1
         check(L.rd_adam_step(_p(table), _p(self.chunks_dev), self.n_chunks, float(self.lr), float(self.mom), float(self.beta2),
-                             float(self.eps), float(self.wd), self.step_count, _p(clip), _stream()), "rd_adam_step")
+                             float(self.eps), float(self.wd), self.step_count, _p(clip), _p(flat), scale, _stream()), "rd_adam_step")
         A.bump_weights_epoch()                 # parameters changed through raw pointers: invalidate cached weight layouts
         return self.norm_out
 
