@@ -44,6 +44,12 @@ def _worker(rank, world, port, q):
     x = torch.full((3, 4), float(rank + 1))
     m(x).sum().backward()
     g = net["student"].weight.grad.clone()
+    # flat-all-reduce mode starts by making every rank equal to rank 0 (parameters AND buffers, mixed dtypes)
+    bn = torch.nn.BatchNorm1d(3)
+    with torch.no_grad():
+        bn.weight.fill_(float(rank + 5)); bn.running_mean.fill_(float(rank + 7)); bn.num_batches_tracked.fill_(rank + 9)
+    D.broadcast_parameters(bn, 0)
+    assert float(bn.weight[0]) == 5.0 and float(bn.running_mean[2]) == 7.0 and int(bn.num_batches_tracked) == 9
     t_max = D.max_over_ranks(0.1 * (rank + 1))
     avg = D.average_scalars([float(rank), 10.0 * rank, 1.0])
     D.barrier()
