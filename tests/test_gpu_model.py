@@ -558,3 +558,65 @@ def test_fused_gelu_grn_forward_backward(B, hw, C):
     close(zd.grad, zr.grad.reshape(B * hw, C), rtol=1e-3, atol=1e-4, what="grad z")
     close(gd.gamma.grad, grn.gamma.grad, rtol=1e-3, atol=1e-4, what="grad gamma")
     close(gd.beta.grad, grn.beta.grad, rtol=1e-3, atol=1e-4, what="grad beta")
+
+
+# ------------------------------------------------------------------------------------------ BASELINE full sizes: size-independent properties
+def test_full_size_training_step_two_arithmetic_modes_agree():
+    """BASELINE configs[3] at its real size (B = 8, 512 x 512 BEV, 35 k + 2 k points, 30 boxes; too big for the CPU oracle):
+    the exact-fp32 kernels and the bf16x3 kernels are two independent implementations of every convolution / weight gradient --
+    one training step in each mode from the same state must agree on the loss, every tb entry and the clipped gradient norm."""
+    from radardistill_amd import kernels as K
+    from radardistill_amd.pcdet.models import model_fn_decorator
+    from radardistill_amd.train import build_optimizer
+    model, cfg, pc_range, voxel, gs = _build_pillarnet(512)
+    sd = model.state_dict(); seeded_fill_(sd, seed=5); model.load_state_dict(sd)
+    model = model.to(DEV).train()
+    init = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    batch = make_batch(batch_size=8, n_lidar=35000, n_radar=2000, n_boxes=30, grid=512, seed=2)
+    out = {}
+    try:
+        for mode in ("f32", "bf16x3"):
+            K.set_conv_math(mode)
+            model.load_state_dict(init)
+            opt = build_optimizer(model, cfg.OPTIMIZATION)
+            opt.zero_grad()
+            loss, tb, _ = model_fn_decorator()(model, {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in batch.items()})
+            loss.backward()
+            norm = opt.step()
+            g = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None])
+            assert torch.isfinite(g).all() and torch.isfinite(loss)
+            out[mode] = (float(loss.detach()), {k: float(v) for k, v in tb.items()}, float(norm[0]), g)
+    finally:
+        K.set_conv_math("f32")
+    (la, ta, na, ga), (lb, tb_, nb, gb) = out["f32"], out["bf16x3"]
+    assert abs(la - lb) <= 1e-3 * abs(la), (la, lb)
+    for k in ta:
+        assert abs(ta[k] - tb_[k]) <= 2e-3 * abs(ta[k]) + 1e-5, (k, ta[k], tb_[k])
+    rel = float((ga - gb).norm() / ga.norm())
+    print("full-size step: loss", la, lb, "grad norm", na, nb, "gradient rel L2 between modes", rel)
+    assert abs(na - nb) <= 5e-2 * na and rel <= 1.5e-1          # ReLU sign flips between two roundings, see test_full_distillation_step_vs_oracle
+
+
+def test_dense_enc_at_1024_bev_size_modes_agree_and_linear():
+    """BASELINE configs[4] shapes (1024 x 1024 BEV -> x_conv4 (B,256,128,128), x_conv5 (B,256,64,64)), eval mode (a fixed affine map
+    up to ReLU): fp32 vs bf16x3 kernels agree, and the map commutes with a batch permutation (no cross-sample leakage)."""
+    from radardistill_amd import kernels as K
+    from radardistill_amd.pcdet.config import AttrDict
+    from radardistill_amd.pcdet.models.backbones_2d import __all__ as REG
+    m = REG["BaseBEVBackboneV2"](AttrDict(BEV_CFG), input_channels=256)
+    sd = m.state_dict(); seeded_fill_(sd, seed=12); m.load_state_dict(sd); m = m.to(DEV).eval()
+    g = np.random.default_rng(4)
+    x4 = torch.from_numpy((g.normal(size=(2, 256, 128, 128)) * (g.uniform(size=(2, 1, 128, 128)) < 0.3)).astype(np.float32))
+    x5 = torch.from_numpy(g.normal(size=(2, 256, 64, 64)).astype(np.float32))
+    res = {}
+    try:
+        for mode in ("f32", "bf16x3"):
+            K.set_conv_math(mode)
+            with torch.no_grad():
+                d = m({"multi_scale_2d_features": {"x_conv4": _cl(x4), "x_conv5": _cl(x5)}})
+                dp = m({"multi_scale_2d_features": {"x_conv4": _cl(x4.flip(0)), "x_conv5": _cl(x5.flip(0))}})
+            res[mode] = (d["spatial_features_2d"].clone(), d["spatial_features_2d_8x"].clone())
+            assert torch.equal(dp["spatial_features_2d"].flip(0), d["spatial_features_2d"])
+    finally:
+        K.set_conv_math("f32")
+    close(res["bf16x3"][0], res["f32"][0], rtol=1e-3, atol=1e-4); close(res["bf16x3"][1], res["f32"][1], rtol=1e-3, atol=1e-4)
