@@ -25,15 +25,24 @@ __global__ __launch_bounds__(NMS_W) void k_nms_mask(int n, float thresh, const f
         if (col_blk >= row_blk) {          // lower-triangle words are never read by the greedy pass
             const float *cur = boxes + (int64_t)i * 7;
             const int start = (row_blk == col_blk) ? threadIdx.x + 1 : 0;
-            for (int j = start; j < col_size; ++j)
-                if (iou_bev(cur, blk + j * 7) > thresh) t |= 1ULL << j;
+            // bounding-circle reject: boxes whose centres are further apart than the sum of their half-diagonals cannot overlap, so
+            // iou_bev would return exactly 0 (never > thresh for thresh >= 0); only the few close pairs pay for the polygon clip
+            const float cx = cur[0], cy = cur[1], cr = 0.5f * sqrtf(cur[3] * cur[3] + cur[4] * cur[4]);
+            for (int j = start; j < col_size; ++j) {
+                const float *o = blk + j * 7;
+                const float dx = o[0] - cx, dy = o[1] - cy, rr = cr + 0.5f * sqrtf(o[3] * o[3] + o[4] * o[4]) + 2e-2f;   // 2e-2 > the 1e-2 inside-box margin of the clip
+                if (thresh >= 0.f && dx * dx + dy * dy > rr * rr) continue;
+                if (iou_bev(cur, o) > thresh) t |= 1ULL << j;
+            }
         }
         mask[(int64_t)i * col_blocks + col_blk] = t;
     }
 }
 
-// Greedy pass by one wavefront: lane l owns the removed-bits words l, l+64, ...; rows are fetched 16 at a time so that the
-// dependent chain sees one memory latency per 16 boxes.
+// Greedy pass by one wavefront, one 64-box block of the matrix at a time.  Lane l owns the removed-bits words l, l+64, ...
+// Inside a block the decisions are sequential (box i is kept unless a kept box before it suppressed it) but only need the 64
+// DIAGONAL words of the block's rows, which are loaded once (lane l <- row 64*cb + l) and walked with register shuffles; the kept
+// rows' other words are then OR-ed into the removed-bits words of the later blocks by independent, back-to-back loads.
 __global__ __launch_bounds__(NMS_W) void k_nms_reduce(int n, const unsigned long long *__restrict__ mask, long long *keep, int *num_keep) {
     constexpr int MAXW = 16;                       // words per lane -> up to 64*16*64 = 65536 boxes
     const int lane = threadIdx.x;
@@ -42,30 +51,35 @@ __global__ __launch_bounds__(NMS_W) void k_nms_reduce(int n, const unsigned long
 #pragma unroll
     for (int k = 0; k < MAXW; ++k) remv[k] = 0;
     int count = 0;
-    for (int i0 = 0; i0 < n; i0 += 16) {
-        // this lane's first word (covers col_blocks <= 64, i.e. n <= 4096) of the next 16 rows, fetched together
-        unsigned long long pre[16];
+    for (int cb = 0; cb < col_blocks; ++cb) {
+        const int row = cb * NMS_W + lane;
+        const unsigned long long diag = row < n ? mask[(int64_t)row * col_blocks + cb] : 0ULL;
+        unsigned long long removed = 0;              // removed-bits word of this block (wave-uniform)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pre[r] = (i0 + r < n && lane < col_blocks) ? mask[(int64_t)(i0 + r) * col_blocks + lane] : 0ULL;
+        for (int k = 0; k < MAXW; ++k)
+            if ((cb >> 6) == k) removed = __shfl(remv[k], cb & 63, NMS_W);
+        const int in_block = min(NMS_W, n - cb * NMS_W);
+        unsigned long long kept = 0;
+        for (int i = 0; i < in_block; ++i) {
+            const unsigned long long d = __shfl(diag, i, NMS_W);
+            if (!((removed >> i) & 1ULL)) {
+                kept |= 1ULL << i;
+                removed |= d;
+            }
+        }
+        // keep list (ascending) and the propagation to the later blocks
+        const int rank = __popcll(kept & ((1ULL << lane) - 1ULL));
+        if ((kept >> lane) & 1ULL) keep[count + rank] = row;
+        count += __popcll(kept);
+        unsigned long long k2 = kept;
+        while (k2) {
+            const int i = __ffsll((long long)k2) - 1;
+            k2 &= k2 - 1;
+            const int64_t r = (int64_t)(cb * NMS_W + i) * col_blocks;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = i0 + r;
-            if (i < n) {
-                const int w = i >> 6;             // word w lives in slot w >> 6 of lane w & 63 (wave-uniform read)
-                unsigned long long word = 0;
-#pragma unroll
-                for (int k = 0; k < MAXW; ++k)
-                    if ((w >> 6) == k) word = __shfl(remv[k], w & 63, NMS_W);
-                if (!((word >> (i & 63)) & 1ULL)) {
-                    if (lane == 0) keep[count] = i;
-                    ++count;
-                    remv[0] |= pre[r];
-#pragma unroll
-                    for (int k = 1; k < MAXW; ++k) {   // n > 4096 only
-                        const int cw = lane + 64 * k;
-                        if (cw < col_blocks) remv[k] |= mask[(int64_t)i * col_blocks + cw];
-                    }
-                }
+            for (int k = 0; k < MAXW; ++k) {
+                const int cw = lane + 64 * k;
+                if (cw > cb && cw < col_blocks) remv[k] |= mask[r + cw];
             }
         }
     }
