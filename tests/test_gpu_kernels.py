@@ -467,3 +467,40 @@ def test_pillar_vfe_and_scatter_golden(golden_dir):
             close(bd["spatial_features"], g["spatial_features"], what="scatter")
     with pytest.raises(NotImplementedError):
         m.train(); m({"voxels": v, "voxel_num_points": n, "voxel_coords": c})     # gradients requested: not built
+
+
+def test_full_size_voxelizer_and_rulebook_pyramid_bit_exact():
+    """BASELINE configs[1]/[3] at their real size (B = 8, 512 x 512 pillars, 35 k LiDAR points per sample): pillar rows of the HIP
+    voxeliser and all four levels of neighbour tables vs the numpy oracle, bit-exact (the oracle's index work is vectorised numpy,
+    seconds at this size)."""
+    A, K, SP = _mods()
+    pc_range, voxel, gs = bench_geometry(512)
+    batch = make_batch(batch_size=8, n_lidar=35000, n_radar=2000, n_boxes=30, grid=512, seed=1)
+    pts = torch.from_numpy(batch["points"])
+    gx, gy = int(gs[0]), int(gs[1])
+    _, _, unq, inv, _ = ovfe.voxelize(pts, pc_range, voxel, (gx, gy))
+    unq = unq.numpy().astype(np.int64)
+    cr = np.stack([unq // (gx * gy), unq % gy, (unq // gy) % gx], axis=1).astype(np.int32)          # key = (b, cx, cy) -> row (b, y, x)
+    rg, point_row = K.voxelize(pts.to(DEV), 8, gx, gy, pc_range[0], pc_range[1], voxel[0], voxel[1])
+    n = int(K.rankgrid_count_tensor(rg, 8 * gx * gy).item())
+    coords = K.rankgrid_coords(rg, 8, gy, gx, True, n)
+    assert n == cr.shape[0] and np.array_equal(coords.cpu().numpy(), cr)
+    pr = point_row.cpu().numpy()
+    assert int((pr >= 0).sum()) == inv.shape[0] and np.array_equal(pr[pr >= 0], inv.numpy())
+    SP.register_rankgrid(coords, rg, True)
+    t = SP.SparseConvTensor(torch.zeros((n, 32), device=DEV), coords, [int(gs[1]), int(gs[0])], 8)
+    idx = cr
+    H, W = int(gs[1]), int(gs[0])
+    for level in range(4):
+        nbr = t._level.subm_spec().fwd_nbr.cpu().numpy()
+        assert np.array_equal(nbr, osp.subm_rulebook(idx, (H, W))), f"SubM table, level {level}"
+        # symmetry of a sub-manifold rulebook: i is tap t of j  <=>  j is tap 8 - t of i
+        o, tt = np.nonzero(nbr >= 0)
+        assert np.array_equal(nbr[nbr[o, tt], 8 - tt], o)
+        if level == 3:
+            break
+        lvl, spec = t._level.down()
+        oidx, oshape, snbr = osp.strided_rulebook(idx, (H, W))
+        assert np.array_equal(lvl.coords.cpu().numpy(), oidx) and np.array_equal(spec.fwd_nbr.cpu().numpy(), snbr), f"strided table, level {level}"
+        t = SP.SparseConvTensor(torch.zeros((oidx.shape[0], 32), device=DEV), lvl.coords, [lvl.H, lvl.W], 8, _level=lvl)
+        idx, (H, W) = oidx, oshape
