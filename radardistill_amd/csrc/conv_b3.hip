@@ -323,6 +323,7 @@ int launch_conv_b3(const ConvArgs &a, int mode, hipStream_t st) {
         if (big_blocks >= 384) k_conv_igemm_b3<128, 128, true><<<dim3(xcd_grid(cdiv(a.out_rows, 128), cdiv(a.Cout, 128))), block, 0, st>>>(a);
         else k_conv_igemm_b3<64, 64, true><<<dim3(xcd_grid(cdiv(a.out_rows, 64), cdiv(a.Cout, 64))), block, 0, st>>>(a);
     } else {
+        // (a 128x64 tile for the 8192-row layers -- 256 workgroups, one per CU -- was measured at 86 vs 116 TF/s for 64x64)
         if (big_blocks >= 384) k_conv_igemm_b3<128, 128, false><<<dim3(xcd_grid(cdiv(a.out_rows, 128), cdiv(a.Cout, 128))), block, 0, st>>>(a);
         else k_conv_igemm_b3<64, 64, false><<<dim3(xcd_grid(cdiv(a.out_rows, 64), cdiv(a.Cout, 64))), block, 0, st>>>(a);
     }
