@@ -75,7 +75,7 @@ class FusedAdamOneCycle:
         self.n_chunks = len(chunks)
         self.chunks_dev = torch.tensor(chunks, dtype=torch.int32, device=dev).contiguous()
         # Descriptor tables go host -> device asynchronously every step (gradient tensors are new allocations each step).  The host
-        # may run a whole step ahead of the GPU (HIP-graph replay), so the pinned staging buffer is a ring: a slot is rewritten only
+        # may run a whole step ahead of the GPU, so the pinned staging buffer is a ring: a slot is rewritten only
         # after the copy that read it has completed (event), never while a DMA may still be reading it.
         nbytes = len(self.params) * ctypes.sizeof(_OptTensor)
         self._ring = 4

@@ -11,9 +11,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
 def test_flat_allreduce_matches_ddp_two_ranks():
     env = dict(os.environ, RD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29577", os.path.join(ROOT, "tests", "dist_flat_check.py")]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_flat_check.py")]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DIST_FLAT_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
