@@ -1,5 +1,7 @@
 """PillarNet with the distillation branches (pcdet/models/detectors/pillarnet.py:12-96): freeze list by class name,
 module chain over a shared batch_dict, three loss modes."""
+import os
+
 import torch
 
 from .detector3d_template import Detector3DTemplate
@@ -28,6 +30,14 @@ class PillarNet(Detector3DTemplate):
         if dev.type == "cuda":
             A.begin_step(dev)
         prepared = False
+        # Frozen teacher on its own HIP stream (training only): after the rulebook pyramids exist, the teacher's backbone / DenseEnc /
+        # head are enqueued on a side stream while the student's modules go to the main stream, so the many kernels of either branch
+        # that do not fill 256 CUs (sparse stages, BatchNorm passes, 64x64-tile convs) overlap.  The student never reads teacher
+        # tensors before the losses; the streams join right before them.  MODEL.TEACHER_STREAM: False / RD_TEACHER_STREAM=0 disables.
+        fork = (dev.type == "cuda" and self.training and bool(self.no_grad_module) and self.model_cfg.get('TEACHER_STREAM', True)
+                and os.environ.get('RD_TEACHER_STREAM', '1') != '0')
+        main = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+        side, forked = None, False
         for cur_module in self.module_list:
             cur_name = cur_module.__class__.__name__
             if not prepared and hasattr(cur_module, 'prepare'):
@@ -41,10 +51,22 @@ class PillarNet(Detector3DTemplate):
                 cur_module.eval()
                 if self.skip_unused_teacher_head and cur_name == 'CenterHead' and self.training:
                     continue
-                with torch.no_grad():          # frozen modules: fused inference kernels, no autograd graph
-                    batch_dict = cur_module(batch_dict)
+                if fork and prepared:
+                    if not forked:
+                        if getattr(self, '_teacher_stream', None) is None:
+                            self._teacher_stream = torch.cuda.Stream(dev)
+                        side = self._teacher_stream
+                        side.wait_stream(main)          # inputs, rulebooks (and last step's readers of recycled teacher memory) are done
+                        forked = True
+                    with torch.cuda.stream(side), torch.no_grad():
+                        batch_dict = cur_module(batch_dict)
+                else:
+                    with torch.no_grad():          # frozen modules: fused inference kernels, no autograd graph
+                        batch_dict = cur_module(batch_dict)
             else:
                 batch_dict = cur_module(batch_dict)
+        if forked:
+            main.wait_stream(side)                  # the losses read teacher feature maps
         if dev.type == "cuda":
             A.end_forward()
         if self.training:
