@@ -132,16 +132,23 @@ class FusedAdamOneCycle:
             self._copied[self._slot] = ev
         return dev_t
 
+    def allreduce_gradients(self, table=None):
+        """Flat-buffer mode: pack every p.grad into self.flat_grad (one launch) and sum it over the ranks (one collective).
+        Returns (flat buffer, scale = 1 / world size), or (None, 1.0) when data parallelism is off / handled by DDP."""
+        if self.flat_grad is None:
+            return None, 1.0
+        import torch.distributed as dist
+        if table is None:
+            table = self._fill_table()
+        check(native.lib().rd_pack_grads(_p(table), _p(self.chunks_dev), self.n_chunks, _p(self.flat_grad), _stream()), "rd_pack_grads")
+        dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.process_group)
+        return self.flat_grad, 1.0 / dist.get_world_size(self.process_group)
+
     def step(self):
         """clip_grad_norm_(grad_clip) + OptimWrapper.step(); returns the device tensor [total_norm, clip_coef]."""
         table = self._fill_table()
         L = native.lib()
-        flat, scale = None, 1.0
-        if self.flat_grad is not None:
-            import torch.distributed as dist
-            check(L.rd_pack_grads(_p(table), _p(self.chunks_dev), self.n_chunks, _p(self.flat_grad), _stream()), "rd_pack_grads")
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.process_group)
-            flat, scale = self.flat_grad, 1.0 / dist.get_world_size(self.process_group)
+        flat, scale = self.allreduce_gradients(table)
         clip = None
         if self.grad_clip is not None and self.grad_clip > 0:
             check(L.rd_grad_norm(_p(table), _p(self.chunks_dev), self.n_chunks, float(self.grad_clip), _p(self.norm_out),
