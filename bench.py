@@ -166,6 +166,17 @@ def main():
     prof, K.CONV_PROFILE = K.CONV_PROFILE, None
     wprof, K.WGRAD_PROFILE = K.WGRAD_PROFILE, None
     last_loss = float(loss.detach())
+    # The timed steps overlap the teacher's kernels (side stream) with the student's, so a launch's event-to-event duration includes
+    # time shared with the other stream.  Two extra steps with the overlap switched off give the kernel's isolated duration.
+    iso_prof = None
+    if os.environ.get("RD_TEACHER_STREAM", "1") != "0":
+        os.environ["RD_TEACHER_STREAM"] = "0"
+        K.CONV_PROFILE = []
+        for it in range(args.warmup + args.steps, args.warmup + args.steps + 2):
+            step(it)
+        torch.cuda.synchronize()
+        iso_prof, K.CONV_PROFILE = K.CONV_PROFILE, None
+        os.environ["RD_TEACHER_STREAM"] = "1"
     # the same step in the other arithmetic mode, for reference (outside the timed region)
     other = None
     if args.other_math_steps > 0:
@@ -214,6 +225,13 @@ def main():
         n_launch = len(sel)
         avg_ms = sum(kernel_ms) / max(n_launch, 1)
         achieved = (sum(flops) / max(n_launch, 1)) / (avg_ms * 1e-3) / 1e12 if n_launch else 0.0
+        iso = None
+        if iso_prof:
+            isel = [p for p in iso_prof if p[4][5] == 128 and p[4][4] < 10]
+            if isel:
+                ims = sum(a.elapsed_time(b) for a, b, _, _, _ in isel) / len(isel)
+                ifl = sum((f if pairs is None else float(pairs.item()) * f) for _, _, pairs, f, _ in isel) / len(isel)
+                iso = (ims, ifl / (ims * 1e-3) / 1e12)
         b3 = args.math == "bf16x3"
         if b3:
             # every algorithmic multiply-add is three bf16 MFMA products (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi): price the kernel
@@ -243,6 +261,11 @@ def main():
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic, "algorithmic_tflops": round(algorithmic, 3),
+                         "isolated": None if iso is None else {
+                             "note": "same launches in 2 extra steps with the teacher/student stream overlap off (in the timed region a launch "
+                                     "shares the GPU with the other stream's kernels, which lengthens it while shortening the step)",
+                             "avg_launch_ms": round(iso[0], 4), "achieved": round(iso[1] * (3.0 if b3 else 1.0), 3),
+                             "frac": round(iso[1] * (3.0 if b3 else 1.0) / peak, 4)},
                          "launches_per_step": n_launch // max(prof_steps, 1), "measured": roofline_note, "avg_launch_ms": round(avg_ms, 4),
                          "time_share_of_step": round(sum(kernel_ms) / prof_steps / (dt / args.steps * 1e3), 4),
                          "all_mfma_conv_fwd_dgrad_share_of_step": round(sum(all_ms) / prof_steps / (dt / args.steps * 1e3), 4)},
