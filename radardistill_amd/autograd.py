@@ -70,16 +70,17 @@ class _GradArena:
         self.high = 0
         self.step_high = 0
 
-    def begin_step(self):
+    def begin_step(self, device=None):
         self.high = max(self.high, self.step_high)
         self.buf, self.off, self.step_high = None, 0, 0
+        if self.high > 0 and device is not None and device.type == "cuda":
+            # allocated and zero-filled HERE, on the forward's stream: slices are handed out later from backward code that may run
+            # under a side stream (weight gradients), and the fill must not be ordered on that stream
+            self.buf = torch.zeros(int(self.high * 1.05) + 4096, dtype=torch.float32, device=device)
 
     def take(self, n, device):
         n_al = (n + 63) // 64 * 64
         self.step_high += n_al
-        if self.buf is None and self.high > 0:
-            self.buf = torch.zeros(int(self.high * 1.05) + 4096, dtype=torch.float32, device=device)
-            self.off = 0
         if self.buf is None or self.buf.device != device or self.off + n_al > self.buf.numel():
             return torch.zeros(n, dtype=torch.float32, device=device)
         out = self.buf[self.off:self.off + n]
@@ -106,8 +107,9 @@ _BN_TOUCHED = []          # BatchNorm modules that ran in train mode this step (
 
 def begin_step(device):
     ARENA.begin_step(device)
-    GRAD_ARENA.begin_step()
+    GRAD_ARENA.begin_step(device)
     _BN_TOUCHED.clear()
+    _WGRAD_JOIN_QUEUED[0] = False
 
 
 def end_forward():
@@ -186,6 +188,36 @@ def split_activation(x):
 
 def _b3_presplit(Cin, Cout, mode):
     return PRESPLIT and K.get_conv_math() == "bf16x3" and Cout > 32 and Cin % 4 == 0 and mode != 3
+
+
+# Weight gradients on a side HIP stream: dgrad feeds the next (earlier) layer's backward, wgrad feeds nobody until the optimizer, so
+# the two GEMMs of a layer need not serialise.  wgrad (+ its layout transform) is launched on a second stream after that stream
+# waited for the producer of grad_out; a callback queued on the autograd engine joins the streams when the backward pass ends, so
+# every consumer of .grad on the main stream is safe.  Off under DistributedDataParallel (its hooks read gradients mid-backward).
+WGRAD_STREAM = [os.environ.get("RD_WGRAD_STREAM", "1") != "0"]
+_WGRAD_STREAMS = {}
+_WGRAD_JOIN_QUEUED = [False]
+
+
+def _wgrad_stream(device):
+    if not WGRAD_STREAM[0] or device.type != "cuda":
+        return None
+    s = _WGRAD_STREAMS.get(device)
+    if s is None:
+        s = _WGRAD_STREAMS[device] = torch.cuda.Stream(device)
+    return s
+
+
+def _queue_wgrad_join(device, main):
+    if _WGRAD_JOIN_QUEUED[0]:
+        return
+    _WGRAD_JOIN_QUEUED[0] = True
+
+    def _join():
+        _WGRAD_JOIN_QUEUED[0] = False
+        main.wait_stream(_WGRAD_STREAMS[device])
+
+    torch.autograd.Variable._execution_engine.queue_callback(_join)
 
 
 class ConvSpec:
@@ -283,6 +315,24 @@ class _ConvFn(torch.autograd.Function):
                     ref.index_add_(0, nb[o, t], grad_out[o].double() @ w3[:, t, :])
                 _dbg_report(f"conv dgrad Cin={Cin} Cout={Cout} rows {spec.out_rows}->{spec.in_rows} flip={spec.bwd_ix.flip}", gx.double(), ref)
         if ctx.needs_input_grad[1]:
+            side = _wgrad_stream(x.device)
+            if side is not None:
+                main = torch.cuda.current_stream(x.device)
+                side.wait_stream(main)                      # grad_out (and the zero-filled accumulator arena) are ready
+                _queue_wgrad_join(x.device, main)
+                with torch.cuda.stream(side):
+                    gw = _ConvFn._wgrad(ctx, x, weight, grad_out, spec, Cout, Cin)
+                x.record_stream(side)                       # the allocator must not recycle these while the side stream reads them
+                grad_out.record_stream(side)
+            else:
+                gw = _ConvFn._wgrad(ctx, x, weight, grad_out, spec, Cout, Cin)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = K.colsum(grad_out) if Cout % 4 == 0 else grad_out.sum(0)
+        return gx, gw, gb, None, None, None
+
+    @staticmethod
+    def _wgrad(ctx, x, weight, grad_out, spec, Cout, Cin):
+        if True:
             if PRESPLIT and K.get_conv_math() == "bf16x3" and Cout >= 64 and Cin >= 64 and Cout % 4 == 0:
                 xs = ctx.xs if ctx.xs is not None else (split_activation(x) if spec.fwd_ix.mode != 3 else None)
                 gwk = K.conv_wgrad(xs if xs is not None else x, split_activation(grad_out), spec.taps, spec.fwd_ix, nbr_keepalive=spec.fwd_nbr,
@@ -295,9 +345,7 @@ class _ConvFn(torch.autograd.Function):
                 gw = K.weight_layout(gwk, Cout, Cin, spec.taps, 4, False, out_shape=tuple(weight.shape))
             else:
                 gw = K.weight_layout(gwk, Cout, Cin, spec.taps, 5, False, out_shape=tuple(weight.shape))
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = K.colsum(grad_out) if Cout % 4 == 0 else grad_out.sum(0)
-        return gx, gw, gb, None, None, None
+            return gw
 
 
 def conv(x, weight, bias, spec, Cout, stats=None):

@@ -69,6 +69,8 @@ def data_parallel(model, optimizer, device_index=None, mode=None):
         return model
     mode = mode or os.environ.get("RD_DDP", "flat")
     if mode == "torch" or not hasattr(optimizer, "enable_flat_allreduce"):
+        from . import autograd as A
+        A.WGRAD_STREAM[0] = False        # DDP's reducer hooks read every gradient the moment autograd produces it, on the main stream
         return wrap_ddp(model, device_index)
     broadcast_parameters(model, 0)
     optimizer.enable_flat_allreduce()
