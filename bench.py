@@ -169,14 +169,18 @@ def main():
     # The timed steps overlap the teacher's kernels (side stream) with the student's, so a launch's event-to-event duration includes
     # time shared with the other stream.  Two extra steps with the overlap switched off give the kernel's isolated duration.
     iso_prof = None
-    if os.environ.get("RD_TEACHER_STREAM", "1") != "0":
+    from radardistill_amd import autograd as A
+    if os.environ.get("RD_TEACHER_STREAM", "1") != "0" or A.WGRAD_STREAM[0]:
+        prev_env, prev_w = os.environ.get("RD_TEACHER_STREAM", "1"), A.WGRAD_STREAM[0]
         os.environ["RD_TEACHER_STREAM"] = "0"
+        A.WGRAD_STREAM[0] = False
         K.CONV_PROFILE = []
         for it in range(args.warmup + args.steps, args.warmup + args.steps + 2):
             step(it)
         torch.cuda.synchronize()
         iso_prof, K.CONV_PROFILE = K.CONV_PROFILE, None
-        os.environ["RD_TEACHER_STREAM"] = "1"
+        os.environ["RD_TEACHER_STREAM"] = prev_env
+        A.WGRAD_STREAM[0] = prev_w
     # the same step in the other arithmetic mode, for reference (outside the timed region)
     other = None
     if args.other_math_steps > 0:
@@ -262,8 +266,8 @@ def main():
                          "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic, "algorithmic_tflops": round(algorithmic, 3),
                          "isolated": None if iso is None else {
-                             "note": "same launches in 2 extra steps with the teacher/student stream overlap off (in the timed region a launch "
-                                     "shares the GPU with the other stream's kernels, which lengthens it while shortening the step)",
+                             "note": "same launches in 2 extra steps with the stream overlaps (teacher || student, wgrad || dgrad) off: in the timed region a "
+                                     "launch shares the GPU with the other streams' kernels, which lengthens it while shortening the step",
                              "avg_launch_ms": round(iso[0], 4), "achieved": round(iso[1] * (3.0 if b3 else 1.0), 3),
                              "frac": round(iso[1] * (3.0 if b3 else 1.0) / peak, 4)},
                          "launches_per_step": n_launch // max(prof_steps, 1), "measured": roofline_note, "avg_launch_ms": round(avg_ms, 4),
