@@ -202,7 +202,8 @@ def main():
     dt = D.max_over_ranks(dt, device)
 
     if rank == 0:
-        print(f"[bench] {args.steps} steps in {dt:.3f} s on {world} GPU(s)", file=sys.stderr, flush=True)
+        print(f"[bench] {args.steps} steps in {dt:.3f} s on {world} GPU(s); peak HBM allocated {torch.cuda.max_memory_allocated(device) / 2**30:.1f} GiB, "
+              f"reserved {torch.cuda.memory_reserved(device) / 2**30:.1f} GiB", file=sys.stderr, flush=True)
         ht = np.array(host_t[-args.steps:]) * 1e3
         print(f"[bench] host enqueue time per step (ms, no device sync): forward+loss {ht[:, 0].mean():.1f}  backward {ht[:, 1].mean():.1f}  "
               f"optimizer {ht[:, 2].mean():.1f}", file=sys.stderr, flush=True)
