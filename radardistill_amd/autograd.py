@@ -220,6 +220,25 @@ def _queue_wgrad_join(device, main):
     torch.autograd.Variable._execution_engine.queue_callback(_join)
 
 
+def param_grad_stream(fn, *inputs):
+    """Run `fn()` -- a launch sequence that only produces PARAMETER gradients (nothing later in this backward pass reads its result)
+    -- on the weight-gradient side stream; `inputs` are the tensors it reads (kept from being recycled under it).  Falls back to a
+    plain call when the side stream is off.  Must be called from inside an autograd Function's backward."""
+    dev = inputs[0].device
+    side = _wgrad_stream(dev)
+    if side is None:
+        return fn()
+    main = torch.cuda.current_stream(dev)
+    side.wait_stream(main)
+    _queue_wgrad_join(dev, main)
+    with torch.cuda.stream(side):
+        out = fn()
+    for t in inputs:
+        if t is not None:
+            t.record_stream(side)
+    return out
+
+
 class ConvSpec:
     """Geometry of one convolution call: how output rows find their input rows, forward and backward.
 
@@ -315,19 +334,9 @@ class _ConvFn(torch.autograd.Function):
                     ref.index_add_(0, nb[o, t], grad_out[o].double() @ w3[:, t, :])
                 _dbg_report(f"conv dgrad Cin={Cin} Cout={Cout} rows {spec.out_rows}->{spec.in_rows} flip={spec.bwd_ix.flip}", gx.double(), ref)
         if ctx.needs_input_grad[1]:
-            side = _wgrad_stream(x.device)
-            if side is not None:
-                main = torch.cuda.current_stream(x.device)
-                side.wait_stream(main)                      # grad_out (and the zero-filled accumulator arena) are ready
-                _queue_wgrad_join(x.device, main)
-                with torch.cuda.stream(side):
-                    gw = _ConvFn._wgrad(ctx, x, weight, grad_out, spec, Cout, Cin)
-                x.record_stream(side)                       # the allocator must not recycle these while the side stream reads them
-                grad_out.record_stream(side)
-            else:
-                gw = _ConvFn._wgrad(ctx, x, weight, grad_out, spec, Cout, Cin)
+            gw = param_grad_stream(lambda: _ConvFn._wgrad(ctx, x, weight, grad_out, spec, Cout, Cin), x, grad_out)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = K.colsum(grad_out) if Cout % 4 == 0 else grad_out.sum(0)
+            gb = param_grad_stream(lambda: K.colsum(grad_out) if Cout % 4 == 0 else grad_out.sum(0), grad_out)
         return gx, gw, gb, None, None, None
 
     @staticmethod
@@ -511,8 +520,8 @@ class _DWConvFn(torch.autograd.Function):
         gw = None
         if ctx.needs_input_grad[1]:
             C = x_rows.shape[1]
-            gw = K_.dwconv_wgrad(x_rows, go, B, H, W, K).t().reshape(C, 1, K, K)
-        gb = K_.colsum(go) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            gw = param_grad_stream(lambda: K_.dwconv_wgrad(x_rows, go, B, H, W, K).t().reshape(C, 1, K, K), x_rows, go)
+        gb = param_grad_stream(lambda: K_.colsum(go), go) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb, None, None, None
 
 
@@ -539,10 +548,10 @@ class _NConvFn(torch.autograd.Function):
         B, H, W = ctx.geom
         go = go.contiguous()
         gy = K.nconv_dgrad(go, weight.detach().contiguous(), B, H, W, ctx.tab, y.shape[1]) if ctx.needs_input_grad[0] else None
-        gw = K.nconv_wgrad(y, go, B, H, W, ctx.tab) if ctx.needs_input_grad[1] else None
+        gw = param_grad_stream(lambda: K.nconv_wgrad(y, go, B, H, W, ctx.tab), y, go) if ctx.needs_input_grad[1] else None
         gb = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = K.colsum(go) if go.shape[1] % 4 == 0 else go.sum(0)
+            gb = param_grad_stream(lambda: K.colsum(go) if go.shape[1] % 4 == 0 else go.sum(0), go)
         return gy, gw, gb, None, None, None, None
 
 

@@ -57,9 +57,10 @@ class _DCNFn(torch.autograd.Function):
         gx = K.dcn_bwd_data(x_rows, colgrad, om_rows, S, om_rows[0:1, 2 * taps:], S, ctx.sig, B, H, W, Ho, Wo, k, stride, pad,
                             g_om, S, g_om[0:1, 2 * taps:], S)
         ix = K.conv_index_deform(samp_idx, samp_w)
-        gwk = K.conv_wgrad(x_rows, go, taps, ix)
-        gw = K.weight_layout(gwk, Cout, Cin, taps, 4, False, out_shape=tuple(weight.shape))
-        gb = (K.colsum(go) if Cout % 4 == 0 else go.sum(0)) if ctx.bias_grad else None
+        # parameter gradients: nobody reads them before the optimizer -> side stream (autograd.param_grad_stream)
+        gw = A.param_grad_stream(lambda: K.weight_layout(K.conv_wgrad(x_rows, go, taps, ix), Cout, Cin, taps, 4, False, out_shape=tuple(weight.shape)),
+                                 x_rows, go, samp_idx, samp_w)
+        gb = A.param_grad_stream(lambda: K.colsum(go) if Cout % 4 == 0 else go.sum(0), go) if ctx.bias_grad else None
         return gx, g_om, gw, gb, None, None
 
 
