@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak (no xf32 on gfx950)
+PEAK_HBM_GBS = 8000.0             # same guide: HBM3E ~8 TB/s
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: dense bf16 matrix peak (the 5 PF headline figure includes 2:1 sparsity)
 
 
@@ -156,6 +157,7 @@ def main():
         torch.cuda.synchronize()
 
     K.CONV_PROFILE = []
+    K.BN_PROFILE = []
     K.WGRAD_PROFILE = [] if os.environ.get("RD_BENCH_SHAPES") else None
     barrier()
     t0 = time.perf_counter()
@@ -164,6 +166,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof, K.CONV_PROFILE = K.CONV_PROFILE, None
+    bnprof, K.BN_PROFILE = K.BN_PROFILE, None
     wprof, K.WGRAD_PROFILE = K.WGRAD_PROFILE, None
     last_loss = float(loss.detach())
     # The timed steps overlap the teacher's kernels (side stream) with the student's, so a launch's event-to-event duration includes
@@ -275,6 +278,18 @@ def main():
                          "time_share_of_step": round(sum(kernel_ms) / prof_steps / (dt / args.steps * 1e3), 4),
                          "all_mfma_conv_fwd_dgrad_share_of_step": round(sum(all_ms) / prof_steps / (dt / args.steps * 1e3), 4)},
         }
+        # HBM side of the metric ("HBM GB/s vs peak"): the streaming train-mode BatchNorm forward (normalise + affine + residual + ReLU,
+        # one launch per layer), algorithmic bytes = x (+ residual) read once, y written once; launches of >= 16 MB only (smaller maps
+        # are launch-latency bound and L2 / Infinity-Cache resident).
+        big = [(a.elapsed_time(b), by) for a, b, by, _ in (bnprof or []) if by >= 16e6]
+        if big:
+            ms_tot, by_tot = sum(t for t, _ in big), sum(b for _, b in big)
+            gbs = by_tot / (ms_tot * 1e-3) / 1e9
+            out["roofline_hbm"] = {"bound": "hbm", "kernel": "k_bn_train_fwd (train-mode BatchNorm + residual + ReLU over rows, launches moving >= 16 MB)",
+                                   "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                   "traffic": None, "launches_per_step": len(big) // max(prof_steps, 1),
+                                   "avg_launch_ms": round(ms_tot / len(big), 4), "algorithmic_bytes_per_launch": int(by_tot / len(big)),
+                                   "measured": "HIP events around every such launch inside the timed region (other streams' kernels run concurrently)"}
         if other is not None:
             out["other_math"] = other
         if world == 1 and not args.no_cpu_baseline:

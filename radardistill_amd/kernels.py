@@ -322,6 +322,11 @@ def bn_stats(x):
     return stats
 
 
+# Optional timing hook for the HBM-bound BatchNorm forward pass (bench.py: achieved GB/s of a streaming kernel next to the MFMA
+# roofline): (start event, end event, algorithmic bytes) per launch.  None = off.
+BN_PROFILE = None
+
+
 def bn_train_fwd(x, stats, gamma, beta, eps, momentum, running_mean, running_var, residual, act):
     """finalize + affine + residual + activation in one launch -> y, (mean, rstd, scale, shift) for the backward pass."""
     _chk(x, f32, "bn input", 2)
@@ -335,8 +340,15 @@ def bn_train_fwd(x, stats, gamma, beta, eps, momentum, running_mean, running_var
             raise RuntimeError(f"bn_train_fwd: {nm} must have {C} elements")
     side = torch.empty((4, C), dtype=f32, device=x.device)
     y = torch.empty_like(x)
+    prof = BN_PROFILE is not None
+    if prof:
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(native.lib().rd_bn_train_fwd(_p(x), rows, C, _p(stats), _p(gamma), _p(beta), eps, momentum, _p(running_mean), _p(running_var),
                                        _p(residual), act, _p(y), _p(side[0]), _p(side[1]), _p(side[2]), _p(side[3]), _stream()), "rd_bn_train_fwd")
+    if prof:
+        e1.record()
+        BN_PROFILE.append((e0, e1, float(rows) * C * 4 * (3 if residual is not None else 2), (rows, C)))   # read x (+ residual), write y
     return y, side[0], side[1], side[2], side[3]
 
 
