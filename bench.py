@@ -77,6 +77,10 @@ def device_batch(batch, device):
         else:
             out[k] = v
     out["gt_boxes_host"] = batch["gt_boxes"]
+    if torch.device(device).type == "cuda":
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        out["_inputs_ready"] = ev              # inputs are resident: the detector's geometry prelude need not wait for the main stream
     return out
 
 

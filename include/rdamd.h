@@ -163,7 +163,8 @@ int rd_conv_wgrad(const float *in, int in_rows, int Cin, const float *grad_out, 
  *   kind 2: data-gradient operand: from kernel layout [Cout][taps][Cin] -> [Cin][taps][Cout], flip reverses taps
  *   kind 3: torch ConvTranspose2d [Cin][Cout][kh][kw] -> kernel layout of the equivalent DENSE_T conv [Cout][taps][Cin]
  *   kind 4: inverse of kind 1 (kernel layout grad -> torch conv layout); kind 5: inverse of kind 3
- *   kind 6: kernel layout [Cout][taps][Cin] -> [taps][Cin][Cout] (DCN column-gradient operand) */
+ *   kind 6: kernel layout [Cout][taps][Cin] -> [taps][Cin][Cout] (DCN column-gradient operand)
+ *   kind 7 / 8: data-gradient operand [Cin][taps][Cout] straight from the torch conv (7) / ConvTranspose2d (8) parameter layout */
 int rd_weight_layout(const float *src, float *dst, int Cout, int Cin, int taps, int kind, int flip, void *stream);
 
 /* column sums: out[C] += sum_j x[j][:] (bias gradients).  ACCUMULATES with fp32 atomics: the caller zero-fills out. */

@@ -173,6 +173,39 @@ def kernel_weight_split(param, wk, Cout, Cin, taps, kind2=False):
     return w
 
 
+# bf16x3 mode, default: only the WEIGHTS are pre-split.  Trainable weights are re-laid-out once per step anyway (torch layout ->
+# [Cout][taps][Cin] for the forward, -> [Cin][taps][Cout] for the data gradient); that launch now writes split format straight from the
+# parameter, so the MFMA kernels skip the weight split in every K step at no extra pass (PMC: the split + addressing VALU work was
+# 6.7 instructions per MFMA in the dense 3x3 kernel).  Frozen (teacher) weights are converted once.
+WSPLIT = os.environ.get("RD_WSPLIT", "1") != "0"
+_DGRAD_KIND = {0: 2, 1: 7, 3: 8}
+
+
+def _b3_wsplit(Cin, Cout):
+    """Cin / Cout of the GEMM being launched (the data gradient swaps them)."""
+    return WSPLIT and not PRESPLIT and K.get_conv_math() == "bf16x3" and Cout > 32 and Cin % 4 == 0
+
+
+def operand_weight_split(param, Cout, Cin, taps, param_kind, dgrad=False):
+    """Parameter (layout `param_kind`: 0 [Cout][taps][Cin], 1 torch Conv2d, 3 torch ConvTranspose2d) -> split-format GEMM operand:
+    [Cout][taps][Cin] for the forward, [Cin][taps][Cout] for the data gradient.  One launch, cached per parameter version."""
+    kind = _DGRAD_KIND[param_kind] if dgrad else param_kind
+
+    def make():
+        src = param.detach()
+        return K.weight_layout_split(src if src.is_contiguous() else src.contiguous(), Cout, Cin, taps, kind, False)
+    if not param.is_leaf:
+        return make()
+    key = (id(param), "op", kind)
+    ver = (param._version, _WEIGHTS_EPOCH[0] if param.requires_grad else -1, param.data_ptr(), Cout, Cin, taps)
+    hit = _SPLIT_W_CACHE.get(key)
+    if hit is not None and hit[0] == ver and hit[2]() is param:
+        return hit[1]
+    w = make()
+    _SPLIT_W_CACHE[key] = (ver, w, weakref.ref(param))
+    return w
+
+
 def split_activation(x):
     """Split-format copy of an activation / gradient tensor, remembered on the tensor object while it is unchanged."""
     hit = getattr(x, "_rd_split", None)
@@ -220,19 +253,57 @@ def _queue_wgrad_join(device, main):
     torch.autograd.Variable._execution_engine.queue_callback(_join)
 
 
-def param_grad_stream(fn, *inputs):
+_PG_STATE = {}          # device -> (main stream of this backward pass, reusable event)
+_set_raw_stream = getattr(torch._C, "_cuda_setStream", None)
+
+
+def _set_stream(s):
+    if _set_raw_stream is not None:
+        _set_raw_stream(stream_id=s.stream_id, device_index=s.device_index, device_type=s.device_type)
+    else:
+        torch.cuda.set_stream(s)
+
+
+def _side_ok(param):
+    """A gradient produced on the side stream must not be READ on the main stream before the join at the end of the backward pass.
+    Autograd only aliases it (AccumulateGrad steals a fresh, layout-conforming tensor; CatBackward hands out views) when the
+    receiving leaf has no .grad yet; with gradient accumulation it runs `p.grad += g` on the main stream, so those cases stay on
+    the main stream.  A non-leaf weight (the concatenated CenterHead branches) names its leaves in `_rd_leaves`."""
+    if param is None:
+        return True
+    if param.is_leaf:
+        return param.grad is None
+    leaves = getattr(param, "_rd_leaves", None)
+    return leaves is not None and all(p.grad is None for p in leaves)
+
+
+def param_grad_stream(fn, *inputs, param=None):
     """Run `fn()` -- a launch sequence that only produces PARAMETER gradients (nothing later in this backward pass reads its result)
     -- on the weight-gradient side stream; `inputs` are the tensors it reads (kept from being recycled under it).  Falls back to a
-    plain call when the side stream is off.  Must be called from inside an autograd Function's backward."""
+    plain call when the side stream is off or `param` (the tensor receiving the gradient) may be read on the main stream (_side_ok).
+    Must be called from inside an autograd Function's backward.
+    Called ~150 times per step, so it avoids the Python-heavy torch.cuda helpers (current_stream / wait_stream / the stream context
+    manager were ~40 us per call, 6 ms of host time per step): the main stream is looked up once per backward pass, the fork is one
+    re-recorded event, and the current stream is switched through the raw setter."""
     dev = inputs[0].device
     side = _wgrad_stream(dev)
-    if side is None:
+    if side is None or not _side_ok(param):
         return fn()
-    main = torch.cuda.current_stream(dev)
-    side.wait_stream(main)
-    _queue_wgrad_join(dev, main)
-    with torch.cuda.stream(side):
+    st = _PG_STATE.get(dev)
+    if st is None or not _WGRAD_JOIN_QUEUED[0]:
+        main = torch.cuda.current_stream(dev)
+        st = _PG_STATE[dev] = (main, st[1] if st is not None else torch.cuda.Event())
+        _queue_wgrad_join(dev, main)
+    main, ev = st
+    ev.record(main)
+    side.wait_event(ev)                       # the wait captures the event's state now; re-recording it later is fine
+    _set_stream(side)
+    try:
         out = fn()
+        if torch.is_tensor(out) and not out.is_contiguous():
+            out = out.contiguous()            # a strided gradient would be CLONED by AccumulateGrad -- on the main stream, unordered
+    finally:
+        _set_stream(main)
     for t in inputs:
         if t is not None:
             t.record_stream(side)
@@ -284,8 +355,18 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, spec, Cout, stats):
         Cin = x.shape[1]
-        wk = kernel_weight(weight, Cout, Cin, spec.taps, spec.param_kind)
         ctx.xs = None
+        if _b3_wsplit(Cin, Cout):
+            wk = None
+            out = K.conv_fwd(x, operand_weight_split(weight, Cout, Cin, spec.taps, spec.param_kind), spec.taps, bias, spec.out_rows, Cout,
+                             spec.fwd_ix, stats=stats, nbr_keepalive=spec.fwd_nbr, w_split=True)
+            ctx.spec, ctx.Cout, ctx.Cin = spec, Cout, Cin
+            ctx.has_bias = bias is not None
+            ctx.bias_ref = bias
+            ctx.wk = None
+            ctx.save_for_backward(x, weight)
+            return out
+        wk = kernel_weight(weight, Cout, Cin, spec.taps, spec.param_kind)
         if _b3_presplit(Cin, Cout, spec.fwd_ix.mode):
             ctx.xs = split_activation(x)              # reused by the weight gradient
             out = K.conv_fwd(ctx.xs, kernel_weight_split(weight, wk, Cout, Cin, spec.taps), spec.taps, bias, spec.out_rows, Cout, spec.fwd_ix,
@@ -294,6 +375,7 @@ class _ConvFn(torch.autograd.Function):
             out = K.conv_fwd(x, wk, spec.taps, bias, spec.out_rows, Cout, spec.fwd_ix, stats=stats, nbr_keepalive=spec.fwd_nbr)
         ctx.spec, ctx.Cout, ctx.Cin = spec, Cout, Cin
         ctx.has_bias = bias is not None
+        ctx.bias_ref = bias
         ctx.wk = wk                                # kernel-layout weights of THIS step (the optimizer runs after backward)
         ctx.save_for_backward(x, weight)
         return out
@@ -306,10 +388,18 @@ class _ConvFn(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             wk = ctx.wk
+            use_ws = wk is None and Cout % 32 == 0 and _b3_wsplit(Cout, Cin)
+            if wk is None and not use_ws:
+                wk = kernel_weight(weight, Cout, Cin, spec.taps, spec.param_kind)
             # exact fp32: the kernel reads the forward weights transposed (no re-layout launch).  bf16x3: the transposed read costs
             # a register transpose per weight tile and measured ~1 ms/step slower than re-laying the weights out once, so that
             # mode keeps the [Cin][taps][Cout] copy (rd_conv_dgrad itself works in both modes).
-            if Cout % 32 == 0 and K.get_conv_math() == "f32":
+            if use_ws:
+                # bf16x3: [Cin][taps][Cout] split-format operand straight from the parameter (unchanged since the forward: the
+                # optimizer runs after backward)
+                wds = operand_weight_split(weight, Cout, Cin, spec.taps, spec.param_kind, dgrad=True)
+                gx = K.conv_fwd(grad_out, wds, spec.taps, None, spec.in_rows, Cin, spec.bwd_ix, nbr_keepalive=spec.bwd_nbr, w_split=True)
+            elif Cout % 32 == 0 and K.get_conv_math() == "f32":
                 gx = K.conv_dgrad(grad_out, wk, spec.taps, spec.in_rows, Cin, spec.bwd_ix, nbr_keepalive=spec.bwd_nbr)   # forward weights, read transposed
             elif Cout % 32 == 0 and _b3_presplit(Cout, Cin, spec.bwd_ix.mode):
                 # bf16x3 with pre-split operands: grad_out is split once (shared with the weight gradient below), the weights are
@@ -326,7 +416,7 @@ class _ConvFn(torch.autograd.Function):
                 wd = K.weight_layout(wk.contiguous(), Cp, Cin, spec.taps, 2, False)          # [Cin][taps][Cout]
                 gx = K.conv_fwd(go, wd, spec.taps, None, spec.in_rows, Cin, spec.bwd_ix, nbr_keepalive=spec.bwd_nbr)
             if _DEBUG and spec.fwd_nbr is not None:
-                w3 = ctx.wk.reshape(-1, spec.taps, Cin)[:Cout].double()
+                w3 = kernel_weight(weight, Cout, Cin, spec.taps, spec.param_kind).reshape(-1, spec.taps, Cin)[:Cout].double()
                 ref = torch.zeros((spec.in_rows, Cin), dtype=torch.float64, device=x.device)
                 nb = spec.fwd_nbr.long()
                 for t in range(spec.taps):
@@ -334,9 +424,9 @@ class _ConvFn(torch.autograd.Function):
                     ref.index_add_(0, nb[o, t], grad_out[o].double() @ w3[:, t, :])
                 _dbg_report(f"conv dgrad Cin={Cin} Cout={Cout} rows {spec.out_rows}->{spec.in_rows} flip={spec.bwd_ix.flip}", gx.double(), ref)
         if ctx.needs_input_grad[1]:
-            gw = param_grad_stream(lambda: _ConvFn._wgrad(ctx, x, weight, grad_out, spec, Cout, Cin), x, grad_out)
+            gw = param_grad_stream(lambda: _ConvFn._wgrad(ctx, x, weight, grad_out, spec, Cout, Cin), x, grad_out, param=weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = param_grad_stream(lambda: K.colsum(grad_out) if Cout % 4 == 0 else grad_out.sum(0), grad_out)
+            gb = param_grad_stream(lambda: K.colsum(grad_out) if Cout % 4 == 0 else grad_out.sum(0), grad_out, param=ctx.bias_ref)
         return gx, gw, gb, None, None, None
 
     @staticmethod
@@ -364,6 +454,9 @@ def conv(x, weight, bias, spec, Cout, stats=None):
 def conv_inference(x, weight, bias, spec, Cout, scale=None, shift=None, residual=None, relu=False):
     """Frozen path (teacher): conv + folded eval-mode BatchNorm + residual + ReLU in ONE kernel, no graph."""
     Cin = x.shape[1]
+    if _b3_wsplit(Cin, Cout):
+        return K.conv_fwd(x, operand_weight_split(weight, Cout, Cin, spec.taps, spec.param_kind), spec.taps, bias, spec.out_rows, Cout,
+                          spec.fwd_ix, scale=scale, shift=shift, residual=residual, relu=relu, nbr_keepalive=spec.fwd_nbr, w_split=True)
     wk = kernel_weight(weight, Cout, Cin, spec.taps, spec.param_kind)
     if _b3_presplit(Cin, Cout, spec.fwd_ix.mode):
         return K.conv_fwd(split_activation(x), kernel_weight_split(weight, wk, Cout, Cin, spec.taps), spec.taps, bias, spec.out_rows, Cout,
@@ -508,6 +601,7 @@ class _DWConvFn(torch.autograd.Function):
         out = K_.dwconv_fwd(x_rows, w_tc, bias.detach() if bias is not None else None, B, H, W, K)
         ctx.geom = (B, H, W, K)
         ctx.has_bias = bias is not None
+        ctx.weight_ref, ctx.bias_ref = weight, bias
         ctx.save_for_backward(x_rows, w_tc)
         return out
 
@@ -520,8 +614,10 @@ class _DWConvFn(torch.autograd.Function):
         gw = None
         if ctx.needs_input_grad[1]:
             C = x_rows.shape[1]
-            gw = param_grad_stream(lambda: K_.dwconv_wgrad(x_rows, go, B, H, W, K).t().reshape(C, 1, K, K), x_rows, go)
-        gb = param_grad_stream(lambda: K_.colsum(go), go) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            # (.t().reshape() alone is a strided VIEW: AccumulateGrad would clone it on the main stream while the side stream still
+            # writes it -- found as a wrong dwconv.weight gradient once the host got fast enough to run ahead)
+            gw = param_grad_stream(lambda: K_.dwconv_wgrad(x_rows, go, B, H, W, K).t().contiguous().view(C, 1, K, K), x_rows, go, param=ctx.weight_ref)
+        gb = param_grad_stream(lambda: K_.colsum(go), go, param=ctx.bias_ref) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb, None, None, None
 
 
@@ -539,6 +635,7 @@ class _NConvFn(torch.autograd.Function):
     def forward(ctx, y, weight, bias, B, H, W, tab):
         out = K.nconv_fwd(y, weight.detach().contiguous(), bias.detach().contiguous() if bias is not None else None, B, H, W, tab)
         ctx.geom, ctx.tab, ctx.has_bias = (B, H, W), tab, bias is not None
+        ctx.bias_ref = bias
         ctx.save_for_backward(y, weight)
         return out
 
@@ -548,10 +645,10 @@ class _NConvFn(torch.autograd.Function):
         B, H, W = ctx.geom
         go = go.contiguous()
         gy = K.nconv_dgrad(go, weight.detach().contiguous(), B, H, W, ctx.tab, y.shape[1]) if ctx.needs_input_grad[0] else None
-        gw = param_grad_stream(lambda: K.nconv_wgrad(y, go, B, H, W, ctx.tab), y, go) if ctx.needs_input_grad[1] else None
+        gw = param_grad_stream(lambda: K.nconv_wgrad(y, go, B, H, W, ctx.tab), y, go, param=weight) if ctx.needs_input_grad[1] else None
         gb = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = param_grad_stream(lambda: K.colsum(go) if go.shape[1] % 4 == 0 else go.sum(0), go)
+            gb = param_grad_stream(lambda: K.colsum(go) if go.shape[1] % 4 == 0 else go.sum(0), go, param=ctx.bias_ref)
         return gy, gw, gb, None, None, None, None
 
 

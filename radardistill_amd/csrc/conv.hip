@@ -654,6 +654,10 @@ __device__ __forceinline__ int64_t layout_src(int64_t i, int Cout, int Cin, int 
         int t = (int)(i % taps), c = (int)((i / taps) % Cin), n = (int)(i / ((int64_t)Cin * taps));
         int ts = flip ? taps - 1 - t : t;
         return ((int64_t)n * taps + ts) * Cin + c;
+    } else if (kind == 7 || kind == 8) {  // torch conv [Cout][Cin][taps] (7) / ConvTranspose2d [Cin][Cout][taps] (8) -> [Cin][taps][Cout]
+        int n = (int)(i % Cout), t = (int)((i / Cout) % taps), c = (int)(i / ((int64_t)Cout * taps));
+        int ts = flip ? taps - 1 - t : t;
+        return kind == 7 ? ((int64_t)n * Cin + c) * taps + ts : ((int64_t)c * Cout + n) * taps + ts;
     } else if (kind == 6) {  // kernel layout [Cout][taps][Cin] -> [taps][Cin][Cout]  (DCN column-gradient operand)
         int n = (int)(i % Cout), c = (int)((i / Cout) % Cin), t = (int)(i / ((int64_t)Cout * Cin));
         return ((int64_t)n * taps + t) * Cin + c;
@@ -689,8 +693,8 @@ __global__ void k_weight_layout_split(const float *src, uint2 *dst_hi_lo, int Co
 
 // destination in split format: kinds whose destination's fastest axis has a multiple-of-4 extent (the K axis of the consuming GEMM)
 extern "C" int rd_weight_layout_split(const float *src, void *dst, int Cout, int Cin, int taps, int kind, int flip, void *stream) {
-    RD_REQUIRE(kind >= 0 && kind <= 3, "rd_weight_layout_split: kinds 0..3 (operand layouts) only, got %d", kind);
-    RD_REQUIRE((kind == 2 ? Cout : Cin) % 4 == 0, "rd_weight_layout_split: the destination's fastest axis must be a multiple of 4");
+    RD_REQUIRE((kind >= 0 && kind <= 3) || kind == 7 || kind == 8, "rd_weight_layout_split: kinds 0..3, 7, 8 (operand layouts) only, got %d", kind);
+    RD_REQUIRE((kind == 2 || kind >= 7 ? Cout : Cin) % 4 == 0, "rd_weight_layout_split: the destination's fastest axis must be a multiple of 4");
     int64_t total = (int64_t)Cout * Cin * taps;
     if (total <= 0) return RD_OK;
     k_weight_layout_split<<<cdiv(total / 4, 256), 256, 0, S(stream)>>>(src, reinterpret_cast<uint2 *>(dst), Cout, Cin, taps, kind, flip);
@@ -698,7 +702,7 @@ extern "C" int rd_weight_layout_split(const float *src, void *dst, int Cout, int
 }
 
 extern "C" int rd_weight_layout(const float *src, float *dst, int Cout, int Cin, int taps, int kind, int flip, void *stream) {
-    RD_REQUIRE(kind >= 0 && kind <= 6, "rd_weight_layout: bad kind %d", kind);
+    RD_REQUIRE(kind >= 0 && kind <= 8, "rd_weight_layout: bad kind %d", kind);
     int64_t total = (int64_t)Cout * Cin * taps;
     if (total <= 0) return RD_OK;
     k_weight_layout<<<cdiv(total, 256), 256, 0, S(stream)>>>(src, dst, Cout, Cin, taps, kind, flip);

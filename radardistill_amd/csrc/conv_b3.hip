@@ -12,6 +12,7 @@
 // part: [rows][32] bf16, 16-byte chunks XOR-swizzled by the row (a 16-lane ds_read_b128 group covers all 64 banks once).  Lane l reads A[row l&31]
 // [k = 8*(l>>5) + 0..7] as one 16-byte fragment (the 32x32x16 bf16 operand map).
 #include <algorithm>
+#include <stdlib.h>
 #include "conv_common.hpp"
 
 using namespace rd;
@@ -316,7 +317,10 @@ int launch_dgrad_b3(const ConvArgs &a, hipStream_t st) {
 }
 
 // Launch for Cout > 32 (narrower outputs stay on the exact-fp32 kernel: they are bandwidth-bound level-1 sparse convs).
+bool launch_conv_d3_b3(const ConvArgs &a, hipStream_t st);
+
 int launch_conv_b3(const ConvArgs &a, int mode, hipStream_t st) {
+    if (launch_conv_d3_b3(a, st)) return RD_OK;      // dense 3x3 stride 1: halo-staged kernel
     const int64_t big_blocks = cdiv(a.out_rows, 128) * cdiv(a.Cout, 128);
     dim3 block(256);
     if (mode == 3) {
@@ -555,4 +559,254 @@ int launch_wgrad_b3(const float *in, int in_rows, int Cin, const float *go, int 
         else k_conv_wgrad_b3<false, 64><<<grid, 256, 0, st>>>(a);
     }
     return RD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- dense 3x3, stride 1: halo-staged bf16x3
+// The gathered kernel above fetches (and splits) every input row once per tap: 9 times for a 3x3 convolution.  For DENSE stride-1
+// 3x3 convolutions (DenseEnc, CMA, head first stages: most of the step's flops) the 9 taps of a TY x TX pixel tile read the same
+// (TY+2) x (TX+2) halo, so this kernel stages and splits the halo ONCE per 32-channel K chunk and walks the 9 taps with shifted
+// LDS fragment addresses: 5.7x (8x16 tile) / 5.8x (8x8) fewer activation loads, splits and LDS writes per MFMA; weights stream per
+// (tap, chunk) as before.  PMC (round 1, 8x64x64 256->256): the first version issued 6.7 VALU instructions per MFMA (weight split,
+// swizzle and address arithmetic), i.e. as many VALU as MFMA cycles; hence
+//   * WS: weights arrive pre-split (rd_weight_layout_split writes them in the per-step re-layout launch that exists anyway),
+//   * halo rows are PADDED (80-byte rows) instead of XOR-swizzled, so a tap is a constant LDS offset, and the 9 taps are unrolled:
+//     fragment addresses are immediates.
+// Same contract as k_conv_igemm_b3 for index mode 1 (and mode 2 = data gradient: taps mirrored, flip = 1, weights in the
+// [Cin][tap][Cout] layout), same epilogue.
+template <int TY, int TX, int BN, bool WS>
+__global__ __launch_bounds__(256, 2) void k_conv_d3_b3(const ConvArgs a, const int flip) {
+    constexpr int BM = TY * TX;
+    constexpr int HX = TX + 2, HR = (TY + 2) * HX;
+    constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32, BP = BN / 32;
+    constexpr int ROW = KB3;    // weight tile: 64-byte rows, chunks XOR-swizzled by the row (as the gathered kernel)
+    constexpr int AROW = 40;    // halo: 80-byte rows (16-byte fragment reads of 16 consecutive rows are conflict-free)
+    static_assert(MI >= 1 && NI >= 1 && BM % 64 == 0, "wave tile at least 32x32");
+    constexpr int A_EL = 2 * HR * AROW, B_EL = 2 * BN * ROW;
+    __shared__ __attribute__((aligned(16))) __bf16 lds[A_EL + 2 * B_EL];
+    __bf16 *Ah = lds, *Al = Ah + HR * AROW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int H = a.ix.Hout, W = a.ix.Wout;
+    const int tiles_x = (W + TX - 1) / TX, tiles_y = (H + TY - 1) / TY;
+    const int n_row_tiles = (a.out_rows / (H * W)) * tiles_y * tiles_x;
+    int row_tile, col_tile;
+    if (!xcd_tile(n_row_tiles, (a.Cout + BN - 1) / BN, row_tile, col_tile)) return;
+    const int b = row_tile / (tiles_y * tiles_x), y0 = ((row_tile / tiles_x) % tiles_y) * TY, x0 = (row_tile % tiles_x) * TX;
+    const int n0 = col_tile * BN;
+    const int ld_r = tid >> 3, ld_c = (tid & 7) * 4;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int kchunks = a.Cin / KB3;
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment bases: A = halo row of this lane's pixel at tap (0,0), chunk fh; B = weight row of this lane
+    const __bf16 *afrag[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int p = wm * WM + i * 32 + fr;
+        afrag[i] = Ah + ((p / TX) * HX + (p % TX)) * AROW + fh * 8;
+    }
+    const int bswz = (fr >> 2) & 3;
+    const int bch0 = ((fh ^ bswz) & 3) << 3, bch1 = (((2 + fh) ^ bswz) & 3) << 3;
+
+    // weight loader: row n0 + ld_r + 32 p, channels kc + ld_c .. +3 of tap wt; rows past Cout read row 0 and are never stored to `out`
+    const float *wrow[BP];
+    int bst[BP];
+#pragma unroll
+    for (int p = 0; p < BP; ++p) {
+        const int n = n0 + ld_r + 32 * p;
+        wrow[p] = a.w + (int64_t)(n < a.Cout ? n : 0) * 9 * a.Cin + ld_c;
+        const int row = ld_r + 32 * p;
+        bst[p] = row * ROW + ((((ld_c >> 3) ^ (row >> 2)) & 3) << 3) + (ld_c & 4);
+    }
+    // ---- pipeline.  Weights: tile s = (chunk, tap) is fetched THREE steps before its MFMAs (two register sets in flight, one LDS
+    // buffer being filled while the other is read).  Halo: the next chunk's rows are fetched at tap 0 and written to LDS after
+    // tap 8.  PMC on the first version: a third of all wave cycles sat in s_waitcnt vmcnt with a one-step prefetch.
+    constexpr int HL = (HR * 8 + 255) / 256;     // float4 halo loads per thread
+    f32x4 rbA[BP], rbB[BP], ra[HL];
+    auto load_B = [&](f32x4 (&r)[BP], int g, int kc) {
+        const int woff = (flip ? 8 - g : g) * a.Cin + kc;
+#pragma unroll
+        for (int p = 0; p < BP; ++p) r[p] = *reinterpret_cast<const f32x4 *>(wrow[p] + woff);
+    };
+    auto store_B = [&](__bf16 *Bh, const f32x4 (&r)[BP]) {
+        __bf16 *Bl = Bh + BN * ROW;
+#pragma unroll
+        for (int p = 0; p < BP; ++p) {
+            bf16x4 hi, lo;
+            if (WS) unpack4(r[p], hi, lo);
+            else split4(r[p], hi, lo);
+            *reinterpret_cast<bf16x4 *>(Bh + bst[p]) = hi;
+            *reinterpret_cast<bf16x4 *>(Bl + bst[p]) = lo;
+        }
+    };
+    auto load_halo = [&](int kc) {
+#pragma unroll
+        for (int q = 0; q < HL; ++q) {
+            const int e = tid + 256 * q;
+            const int hr = e >> 3, c4 = (e & 7) * 4;
+            const int gy = y0 - 1 + hr / HX, gx = x0 - 1 + hr % HX;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (e < HR * 8 && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = *reinterpret_cast<const f32x4 *>(a.in + ((int64_t)(b * H + gy) * W + gx) * a.Cin + kc + c4);
+            ra[q] = v;
+        }
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int q = 0; q < HL; ++q) {
+            const int e = tid + 256 * q;
+            if (e < HR * 8) {
+                const int hr = e >> 3, c4 = (e & 7) * 4;
+                bf16x4 hi, lo;
+                split4(ra[q], hi, lo);
+                *reinterpret_cast<bf16x4 *>(Ah + hr * AROW + c4) = hi;
+                *reinterpret_cast<bf16x4 *>(Al + hr * AROW + c4) = lo;
+            }
+        }
+    };
+
+    __bf16 *bcur = lds + A_EL, *bnext = bcur + B_EL;
+    load_halo(0);
+    load_B(rbA, 0, 0);
+    store_halo();
+    store_B(bcur, rbA);
+    load_B(rbA, 1, 0);            // tile s+1
+    load_B(rbB, 2, 0);            // tile s+2
+    __syncthreads();
+
+    for (int kq = 0; kq < kchunks; ++kq) {
+        const int kc = kq * KB3;
+        const bool more = kq + 1 < kchunks;
+        if (more) load_halo(kc + KB3);
+#pragma unroll
+        for (int g = 0; g < 9; ++g) {
+            const int shift = ((g / 3) * HX + g % 3) * AROW;        // compile-time per unrolled tap
+            const __bf16 *Bh = bcur + (wn * WN + fr) * ROW, *Bl = Bh + BN * ROW;
+#pragma unroll
+            for (int ks = 0; ks < KB3 / 16; ++ks) {
+                bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    ah[i] = *reinterpret_cast<const bf16x8 *>(afrag[i] + shift + ks * 16);
+                    al[i] = *reinterpret_cast<const bf16x8 *>(afrag[i] + HR * AROW + shift + ks * 16);
+                }
+                const int bch = ks ? bch1 : bch0;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    bh[j] = *reinterpret_cast<const bf16x8 *>(Bh + j * 32 * ROW + bch);
+                    bl[j] = *reinterpret_cast<const bf16x8 *>(Bl + j * 32 * ROW + bch);
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+            // here rbA = tile s+1, rbB = tile s+2 (s = kq * 9 + g)
+            if (g + 1 < 9 || more) store_B(bnext, rbA);        // bnext was last read in step s-1, which ended with a barrier
+            if (g + 3 < 9) load_B(rbA, g + 3, kc);
+            else if (more) load_B(rbA, g + 3 - 9, kc + KB3);
+#pragma unroll
+            for (int p = 0; p < BP; ++p) {
+                const f32x4 t = rbA[p];
+                rbA[p] = rbB[p];
+                rbB[p] = t;
+            }
+            __bf16 *tb = bcur;
+            bcur = bnext;
+            bnext = tb;
+            __syncthreads();
+        }
+        if (more) {
+            store_halo();          // every wave passed the barrier of tap 8: nobody reads the old halo any more
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue (as k_conv_igemm_b3; tile rows are pixels of the (TY, TX) patch)
+    float *red = reinterpret_cast<float *>(lds);
+    if (a.stats) {
+        for (int i = tid; i < 2 * BN; i += 256) red[i] = 0.f;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int col = n0 + wn * WN + j * 32 + fr;
+        const bool col_ok = col < a.Cout;
+        const float bias = (a.bias && col_ok) ? a.bias[col] : 0.f;
+        const float sc = (a.scale && col_ok) ? a.scale[col] : 1.f;
+        const float sh = (a.shift && col_ok) ? a.shift[col] : 0.f;
+        float csum = 0.f, csq = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int gy = y0 + p / TX, gx = x0 + p % TX;
+                if (gy < H && gx < W && col_ok) {
+                    const int64_t row = (int64_t)(b * H + gy) * W + gx;
+                    float v = acc[i][j][r] + bias;
+                    csum += v;
+                    csq += v * v;
+                    v = fmaf(v, sc, sh);
+                    if (a.residual) v += a.residual[row * a.Cout + col];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    a.out[row * a.Cout + col] = v;
+                }
+            }
+        }
+        if (a.stats && col_ok) {
+            atomicAdd(&red[wn * WN + j * 32 + fr], csum);
+            atomicAdd(&red[BN + wn * WN + j * 32 + fr], csq);
+        }
+    }
+    if (a.stats) {
+        __syncthreads();
+        for (int i = tid; i < BN; i += 256) {
+            const int col = n0 + i;
+            if (col < a.Cout) {
+                atomicAdd(&a.stats[col], red[i]);
+                atomicAdd(&a.stats[a.Cout + col], red[BN + i]);
+            }
+        }
+    }
+}
+
+// true when the halo kernel applies; launches it (mode 1 forward or mode 2 = stride-1 data gradient, 3x3, pad 1, fp32 activations,
+// weights fp32 or pre-split)
+bool launch_conv_d3_b3(const ConvArgs &a, hipStream_t st) {
+    const rd_conv_index &ix = a.ix;
+    if (!((ix.mode == 1 || ix.mode == 2) && ix.KH == 3 && ix.KW == 3 && ix.stride == 1 && ix.pad == 1 && ix.Hin == ix.Hout && ix.Win == ix.Wout))
+        return false;
+    if (a.in_split || a.taps != 9 || a.Cin % KB3) return false;
+    static const bool off = getenv("RD_D3") && getenv("RD_D3")[0] == '0';
+    if (off) return false;
+    const int flip = ix.mode == 2;
+    const int64_t nb = a.out_rows / ((int64_t)ix.Hout * ix.Wout);
+    if (nb * ix.Hout * ix.Wout != a.out_rows || a.in_rows != a.out_rows) return false;
+    const int64_t big_rows = nb * cdiv(ix.Hout, 8) * cdiv(ix.Wout, 16);
+    dim3 block(256);
+    if (big_rows * cdiv(a.Cout, 128) >= 384) {
+        const dim3 grid(xcd_grid(big_rows, cdiv(a.Cout, 128)));
+        if (a.w_split) k_conv_d3_b3<8, 16, 128, true><<<grid, block, 0, st>>>(a, flip);
+        else k_conv_d3_b3<8, 16, 128, false><<<grid, block, 0, st>>>(a, flip);
+    } else {
+        const int64_t rows64 = nb * cdiv(ix.Hout, 8) * cdiv(ix.Wout, 8);
+        const dim3 grid(xcd_grid(rows64, cdiv(a.Cout, 64)));
+        if (a.w_split) k_conv_d3_b3<8, 8, 64, true><<<grid, block, 0, st>>>(a, flip);
+        else k_conv_d3_b3<8, 8, 64, false><<<grid, block, 0, st>>>(a, flip);
+    }
+    return true;
 }

@@ -14,7 +14,15 @@ from .native import ConvIndex, check
 f32, i32 = torch.float32, torch.int32
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """Current HIP stream of the current device as a raw handle.  torch.cuda.current_stream() costs ~9 us of Python per call
+    (measured: 2.6 ms of a 30 ms step over ~300 launches in the forward alone); the two C entry points below cost ~0.3 us."""
+    if _raw_stream is not None and _raw_device is not None:
+        return ctypes.c_void_p(_raw_stream(_raw_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -170,7 +178,7 @@ def split_bf16(x):
 
 
 def weight_layout_split(src, Cout, Cin, taps, kind, flip=False):
-    """Like weight_layout (kinds 0..3) with the destination written in split format."""
+    """Like weight_layout (operand kinds 0..3, 7, 8) with the destination written in split format."""
     _chk(src, f32, "weight")
     if src.numel() != Cout * Cin * taps:
         raise RuntimeError("weight_layout_split: element count mismatch")

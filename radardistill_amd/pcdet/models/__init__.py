@@ -12,10 +12,21 @@ def build_network(model_cfg, num_class, dataset):
     return build_detector(model_cfg=model_cfg, num_class=num_class, dataset=dataset)
 
 
+_COPY_STREAM = {}
+
+
 def load_data_to_gpu(batch_dict):
     """numpy -> float32 CUDA tensors (reference: pageable `.cuda()` per key).  Host arrays go through pinned staging and
-    non-blocking copies; `gt_boxes` additionally keeps a host copy (`gt_boxes_host`) so the CPU-side target assignment
-    does not have to read it back."""
+    non-blocking copies on a copy stream; `gt_boxes` additionally keeps a host copy (`gt_boxes_host`) so the CPU-side target
+    assignment does not have to read it back.  batch_dict['_inputs_ready'] is an event recorded after the last copy: the
+    detector's geometry prelude (detectors/pillarnet.py) waits for it instead of for the whole main stream."""
+    cuda = torch.cuda.is_available()
+    uploaded = []
+    if cuda:
+        dev = torch.cuda.current_device()
+        cs = _COPY_STREAM.get(dev)
+        if cs is None:
+            cs = _COPY_STREAM[dev] = torch.cuda.Stream(dev)
     for key, val in list(batch_dict.items()):
         if not isinstance(val, np.ndarray):
             continue
@@ -24,10 +35,22 @@ def load_data_to_gpu(batch_dict):
         if key == 'gt_boxes':
             batch_dict['gt_boxes_host'] = val
         if key in ['image_shape']:
-            batch_dict[key] = torch.from_numpy(val).int().cuda(non_blocking=True)
+            t = torch.from_numpy(val).int()
         else:
             t = torch.from_numpy(np.ascontiguousarray(val, dtype=np.float32))
-            batch_dict[key] = t.pin_memory().cuda(non_blocking=True) if torch.cuda.is_available() else t
+        if cuda:
+            with torch.cuda.stream(cs):
+                t = t.pin_memory().cuda(non_blocking=True)
+            uploaded.append(t)
+        batch_dict[key] = t
+    if uploaded:
+        ev = torch.cuda.Event()
+        ev.record(cs)
+        main = torch.cuda.current_stream()
+        main.wait_event(ev)
+        for t in uploaded:
+            t.record_stream(main)
+        batch_dict['_inputs_ready'] = ev
 
 
 def model_fn_decorator():

@@ -82,21 +82,42 @@ class DynamicPillarVFESimple2D(VFETemplate):
     def get_output_feature_dim(self):
         return self.num_filters[-1]
 
-    def forward(self, batch_dict, **kwargs):
+    def _points(self, batch_dict):
         points = batch_dict[self.POINTS_KEY]
         if points.dtype != torch.float32 or not points.is_contiguous():
             points = points.float().contiguous()
         if points.shape[1] != 1 + self.raw_point_features:
             raise RuntimeError(f"{self.POINTS_KEY}: expected {1 + self.raw_point_features} columns, got {points.shape[1]}")
+        return points
+
+    def geometry_begin(self, batch_dict):
+        """Index half of the VFE, part 1: points -> rank grid + point->pillar rows.  Returns the launch state and the two device
+        scalars (pillar count, in-range point count) the host needs; detectors/pillarnet.py reads them for all branches at once."""
+        points = self._points(batch_dict)
         B = int(batch_dict['batch_size'])
-        gx, gy = self.grid_x, self.grid_y
-        # torch.tensor(voxel_size) in the reference is fp32: divide by the fp32 voxel size
+        rg, point_row = K.voxelize(points, B, self.grid_x, self.grid_y, self.pc_range[0], self.pc_range[1], self.voxel_x, self.voxel_y)
+        cnt = K.rankgrid_count_tensor(rg, B * self.grid_x * self.grid_y)
+        return (points, rg, point_row, B), [cnt.long(), (point_row >= 0).sum()]
+
+    def geometry_finish(self, batch_dict, state, P, n_valid):
+        """Part 2: pillar coordinates, registered with their rank grid (and a `_Level` the sparse backbone will adopt)."""
+        points, rg, point_row, B = state
+        coords = K.rankgrid_coords(rg, B, self.grid_y, self.grid_x, True, P)     # (b, y, x), rows in (b, cx, cy) key order
+        level = SP._Level(coords, rg, True, B, self.grid_y, self.grid_x)
+        SP.register_rankgrid(coords, rg, True, level)
+        batch_dict[self.OUT_PREFIX + '_vfe_geometry'] = (points, rg, point_row, coords, P, n_valid)
+        return level
+
+    def forward(self, batch_dict, **kwargs):
+        geo = batch_dict.pop(self.OUT_PREFIX + '_vfe_geometry', None)
+        if geo is None:
+            state, scalars = self.geometry_begin(batch_dict)
+            P, n_valid = [int(v) for v in torch.stack(scalars).tolist()]          # one device->host sync
+            self.geometry_finish(batch_dict, state, P, n_valid)
+            geo = batch_dict.pop(self.OUT_PREFIX + '_vfe_geometry')
+        points, rg, point_row, coords, P, n_valid = geo
+        B = int(batch_dict['batch_size'])
         g = self._geom
-        rg, point_row = K.voxelize(points, B, gx, gy, self.pc_range[0], self.pc_range[1], self.voxel_x, self.voxel_y)
-        cnt = K.rankgrid_count_tensor(rg, B * gx * gy)
-        P, n_valid = [int(v) for v in torch.stack([cnt.long(), (point_row >= 0).sum()]).tolist()]     # one device->host sync
-        coords = K.rankgrid_coords(rg, B, gy, gx, True, P)                     # (b, y, x), rows in (b, cx, cy) key order
-        SP.register_rankgrid(coords, rg, True)
         acc = K.vfe_pillar_mean(points, point_row, P)
         pfn = self.pfn_layers[0]
         w, bn = pfn.linear.weight, pfn.norm

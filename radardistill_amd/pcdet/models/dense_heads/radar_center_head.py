@@ -141,6 +141,9 @@ class _BranchBatch:
         elif training:
             w1 = torch.cat([b[2].weight for b in self.branches], 0)
             b1 = torch.cat([b[2].bias for b in self.branches]) if self.branches[0][2].bias is not None else None
+            w1._rd_leaves = [b[2].weight for b in self.branches]          # who receives the gradient (autograd.param_grad_stream)
+            if b1 is not None:
+                b1._rd_leaves = [b[2].bias for b in self.branches]
             stats = A.zeros_stats(2 * C1, rows.device)
             raw = A.conv(rows, w1, b1, spec, C1, stats)
             gamma = torch.cat([bn.weight for bn in bns])
@@ -154,6 +157,8 @@ class _BranchBatch:
                 torch._foreach_copy_([bn.running_var for bn in bns], list(rv.split(64)))
             w2 = torch.cat([b[4].weight for b in self.branches], 0)
             b2 = torch.cat([b[4].bias for b in self.branches])
+            w2._rd_leaves = [b[4].weight for b in self.branches]
+            b2._rd_leaves = [b[4].bias for b in self.branches]
             out = A.nconv(y, w2, b2, B, H, W, self.tab)
         else:
             return None                       # eval-mode BatchNorm with gradients: rare, the per-branch path handles it

@@ -37,6 +37,7 @@ class _DCNFn(torch.autograd.Function):
         ctx.geom, ctx.sig, ctx.out_hw = geom, sig, (Ho, Wo)
         ctx.save_for_backward(x_rows, om_rows, weight, samp_idx, samp_w)
         ctx.bias_grad = bias.requires_grad
+        ctx.bias_ref = bias
         return out
 
     @staticmethod
@@ -59,8 +60,8 @@ class _DCNFn(torch.autograd.Function):
         ix = K.conv_index_deform(samp_idx, samp_w)
         # parameter gradients: nobody reads them before the optimizer -> side stream (autograd.param_grad_stream)
         gw = A.param_grad_stream(lambda: K.weight_layout(K.conv_wgrad(x_rows, go, taps, ix), Cout, Cin, taps, 4, False, out_shape=tuple(weight.shape)),
-                                 x_rows, go, samp_idx, samp_w)
-        gb = A.param_grad_stream(lambda: K.colsum(go) if Cout % 4 == 0 else go.sum(0), go) if ctx.bias_grad else None
+                                 x_rows, go, samp_idx, samp_w, param=weight)
+        gb = A.param_grad_stream(lambda: K.colsum(go) if Cout % 4 == 0 else go.sum(0), go, param=ctx.bias_ref) if ctx.bias_grad else None
         return gx, g_om, gw, gb, None, None
 
 

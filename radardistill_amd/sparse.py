@@ -22,10 +22,11 @@ from . import kernels as K
 _RANKGRID_REGISTRY = {}
 
 
-def register_rankgrid(coords, rankgrid, xmajor):
+def register_rankgrid(coords, rankgrid, xmajor, level=None):
+    """Remember the rank grid (and optionally the whole prebuilt `_Level` pyramid) that belongs to a pillar_coords tensor."""
     while len(_RANKGRID_REGISTRY) >= 4:          # teacher + student of the current step (+ the previous step's); bounded
         _RANKGRID_REGISTRY.pop(next(iter(_RANKGRID_REGISTRY)))
-    _RANKGRID_REGISTRY[(coords.data_ptr(), tuple(coords.shape))] = (rankgrid, xmajor, coords)
+    _RANKGRID_REGISTRY[(coords.data_ptr(), tuple(coords.shape))] = (rankgrid, xmajor, coords, level)
 
 
 class _Level:
@@ -46,19 +47,59 @@ class _Level:
             self._subm = A.ConvSpec(9, self.n, self.n, fwd, bwd, 0, keep=(nbr,), fwd_nbr=nbr, bwd_nbr=nbr)
         return self._subm
 
+    def down_begin(self):
+        """First half of down(): the output rank grid and its (device) active-cell count."""
+        Ho, Wo = (self.H + 2 - 3) // 2 + 1, (self.W + 2 - 3) // 2 + 1
+        rg_o = K.rankgrid_downsample(self.coords, self.batch, Ho, Wo)
+        return rg_o, K.rankgrid_count_tensor(rg_o, self.batch * Ho * Wo)
+
+    def down_finish(self, rg_o, n_out):
+        Ho, Wo = (self.H + 2 - 3) // 2 + 1, (self.W + 2 - 3) // 2 + 1
+        coords_o = K.rankgrid_coords(rg_o, self.batch, Ho, Wo, False, n_out)
+        nbr = K.nbr_strided(coords_o, self.rg, self.batch, self.H, self.W, self.xmajor)
+        nbrT = K.nbr_strided_T(self.coords, rg_o, self.batch, Ho, Wo)
+        spec = A.ConvSpec(9, self.n, n_out, K.conv_index_table(nbr), K.conv_index_table(nbrT), 0, keep=(nbr, nbrT),
+                          fwd_nbr=nbr, bwd_nbr=nbrT)
+        self._down = (_Level(coords_o, rg_o, False, self.batch, Ho, Wo), spec)
+        return self._down
+
     def down(self):
         """SparseConv2d(k3, s2, p1) output level + conv spec."""
         if self._down is None:
-            Ho, Wo = (self.H + 2 - 3) // 2 + 1, (self.W + 2 - 3) // 2 + 1
-            rg_o = K.rankgrid_downsample(self.coords, self.batch, Ho, Wo)
-            n_out = int(K.rankgrid_count_tensor(rg_o, self.batch * Ho * Wo).item())        # device -> host sync
-            coords_o = K.rankgrid_coords(rg_o, self.batch, Ho, Wo, False, n_out)
-            nbr = K.nbr_strided(coords_o, self.rg, self.batch, self.H, self.W, self.xmajor)
-            nbrT = K.nbr_strided_T(self.coords, rg_o, self.batch, Ho, Wo)
-            spec = A.ConvSpec(9, self.n, n_out, K.conv_index_table(nbr), K.conv_index_table(nbrT), 0, keep=(nbr, nbrT),
-                              fwd_nbr=nbr, bwd_nbr=nbrT)
-            self._down = (_Level(coords_o, rg_o, False, self.batch, Ho, Wo), spec)
+            rg_o, cnt = self.down_begin()
+            self.down_finish(rg_o, int(cnt.item()))                                        # device -> host sync
         return self._down
+
+    def tensors(self):
+        """Every device tensor of this level and the levels below it (for record_stream when built on another stream)."""
+        yield self.coords
+        yield self.rg
+        if self._subm is not None:
+            yield self._subm.fwd_nbr
+        if self._down is not None:
+            lvl, spec = self._down
+            yield spec.fwd_nbr
+            yield spec.bwd_nbr
+            yield from lvl.tensors()
+
+
+def build_pyramids(levels, n_down):
+    """SubM tables + `n_down` stride-2 levels below each of `levels`, in lockstep: ONE device->host read per depth for all branches."""
+    cur = list(levels)
+    for lvl in cur:
+        lvl.subm_spec()
+    for _ in range(n_down):
+        begun = [lvl.down_begin() if lvl._down is None else None for lvl in cur]
+        pending = [b[1] for b in begun if b is not None]
+        counts = iter(torch.stack(pending).tolist()) if pending else iter(())
+        nxt = []
+        for lvl, b in zip(cur, begun):
+            if b is not None:
+                lvl.down_finish(b[0], int(next(counts)))
+            nxt.append(lvl._down[0])
+        cur = nxt
+        for lvl in cur:
+            lvl.subm_spec()
 
 
 class SparseConvTensor:
@@ -74,11 +115,15 @@ class SparseConvTensor:
                 indices = indices.int().contiguous()
                 self.indices = indices
             hit = _RANKGRID_REGISTRY.get((indices.data_ptr(), tuple(indices.shape)))
-            if hit is not None:
-                rg, xmajor = hit[0], hit[1]
+            lvl = hit[3] if hit is not None else None
+            if lvl is not None and (lvl.batch, lvl.H, lvl.W) == (self.batch_size, H, W):
+                _level = lvl                          # pyramid prebuilt by the geometry prelude (detectors/pillarnet.py)
             else:
-                rg, xmajor = self._rankgrid_from_user_indices(indices, H, W)
-            _level = _Level(indices, rg, xmajor, self.batch_size, H, W)
+                if hit is not None:
+                    rg, xmajor = hit[0], hit[1]
+                else:
+                    rg, xmajor = self._rankgrid_from_user_indices(indices, H, W)
+                _level = _Level(indices, rg, xmajor, self.batch_size, H, W)
         self._level = _level
 
     def _rankgrid_from_user_indices(self, idx, H, W):
