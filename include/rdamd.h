@@ -136,6 +136,15 @@ int rd_get_conv_math(void);
  * (bf16x3 mode only; an input sampled by a deformable index must stay fp32). */
 int rd_split_bf16(const float *x, int64_t n, void *out, void *stream);
 int rd_weight_layout_split(const float *src, void *dst, int Cout, int Cin, int taps, int kind, int flip, void *stream);
+/* The same conversion for MANY weights in one launch (all trainable conv weights once per optimizer step).  jobs_dev: device array of
+ * jobs (kinds as rd_weight_layout_split, no tap flip); chunk c (one 256-thread workgroup) converts 256 groups of 4 destination
+ * elements of job chunk_job[c] starting at group chunk_group[c]; the caller builds the chunk tables so that every job is covered. */
+typedef struct {
+    const float *src;
+    void *dst;
+    int Cout, Cin, taps, kind;
+} rd_layout_job;
+int rd_weight_layout_split_multi(const rd_layout_job *jobs_dev, const int *chunk_job_dev, const int *chunk_group_dev, int n_chunks, void *stream);
 int rd_conv_fwd_split(const void *in, int in_is_split, int in_rows, int Cin, const void *weight_k, int w_is_split, int taps,
                       const float *bias, float *out, int out_rows, int Cout, const rd_conv_index *idx, const float *scale,
                       const float *shift, const float *residual, int relu, float *stats, void *stream);

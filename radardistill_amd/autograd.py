@@ -108,6 +108,8 @@ _BN_TOUCHED = []          # BatchNorm modules that ran in train mode this step (
 def begin_step(device):
     ARENA.begin_step(device)
     GRAD_ARENA.begin_step(device)
+    if device.type == "cuda":
+        _OPERANDS.refresh_all(device)
     _BN_TOUCHED.clear()
     _WGRAD_JOIN_QUEUED[0] = False
 
@@ -186,24 +188,85 @@ def _b3_wsplit(Cin, Cout):
     return WSPLIT and not PRESPLIT and K.get_conv_math() == "bf16x3" and Cout > 32 and Cin % 4 == 0
 
 
+class _OperandCache:
+    """Split-format GEMM operands of leaf parameters in PERSISTENT buffers.  Entries that went stale (the fused optimizer bumped the
+    weights epoch, or torch bumped param._version) are re-converted together by refresh_all() -- one launch per step, issued from
+    begin_step() -- instead of one small launch per weight per direction (~106 per step); a request for a stale or new entry outside
+    that rhythm converts it alone.  Refreshing in place is safe: every reader of the previous contents was enqueued earlier on the
+    same (main) stream; the teacher's stream only reads frozen entries, which are never rewritten."""
+
+    def __init__(self):
+        self.entries = {}        # (id(param), kind) -> [ver, dst, weakref(param), Cout, Cin, taps, kind]
+        self.table = None        # (signature, jobs_dev, chunk_job_dev, chunk_group_dev, n_chunks, keys)
+
+    @staticmethod
+    def _ver(param):
+        return (param._version, _WEIGHTS_EPOCH[0] if param.requires_grad else -1, param.data_ptr())
+
+    def get(self, param, Cout, Cin, taps, kind):
+        key = (id(param), kind)
+        e = self.entries.get(key)
+        ver = self._ver(param)
+        if e is not None and e[2]() is param and (e[3], e[4], e[5]) == (Cout, Cin, taps):
+            if e[0] != ver:
+                src = param.detach()
+                K.weight_layout_split(src if src.is_contiguous() else src.contiguous(), Cout, Cin, taps, kind, False, out=e[1])
+                e[0] = ver
+            return e[1]
+        src = param.detach()
+        dst = K.weight_layout_split(src if src.is_contiguous() else src.contiguous(), Cout, Cin, taps, kind, False)
+        self.entries[key] = [ver, dst, weakref.ref(param), Cout, Cin, taps, kind]
+        self.table = None
+        return dst
+
+    def refresh_all(self, device):
+        """Re-convert every stale entry of a live, contiguous parameter on `device` in one launch."""
+        stale = []
+        for key, e in list(self.entries.items()):
+            p = e[2]()
+            if p is None:
+                del self.entries[key]
+                self.table = None
+                continue
+            if p.device == device and p.is_contiguous() and e[0] != self._ver(p):
+                stale.append((key, e, p))
+        if not stale:
+            return
+        sig = tuple((key, p.data_ptr()) for key, e, p in stale)
+        if self.table is None or self.table[0] != sig:
+            import numpy as np
+            from .native import LayoutJob
+            jobs = (LayoutJob * len(stale))()
+            cj, cg = [], []
+            for i, (key, e, p) in enumerate(stale):
+                jobs[i].src, jobs[i].dst = p.data_ptr(), e[1].data_ptr()
+                jobs[i].Cout, jobs[i].Cin, jobs[i].taps, jobs[i].kind = e[3], e[4], e[5], e[6]
+                groups = (e[3] * e[4] * e[5]) // 4
+                starts = np.arange(0, groups, 256, dtype=np.int32)
+                cj.append(np.full(starts.shape, i, dtype=np.int32))
+                cg.append(starts)
+            raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(device)
+            cj_d = torch.from_numpy(np.concatenate(cj)).to(device)
+            cg_d = torch.from_numpy(np.concatenate(cg)).to(device)
+            self.table = (sig, raw, cj_d, cg_d, int(cj_d.numel()))
+        _, raw, cj_d, cg_d, n = self.table
+        K.weight_layout_split_multi(raw, cj_d, cg_d, n)
+        for key, e, p in stale:
+            e[0] = self._ver(p)
+
+
+_OPERANDS = _OperandCache()
+
+
 def operand_weight_split(param, Cout, Cin, taps, param_kind, dgrad=False):
     """Parameter (layout `param_kind`: 0 [Cout][taps][Cin], 1 torch Conv2d, 3 torch ConvTranspose2d) -> split-format GEMM operand:
-    [Cout][taps][Cin] for the forward, [Cin][taps][Cout] for the data gradient.  One launch, cached per parameter version."""
+    [Cout][taps][Cin] for the forward, [Cin][taps][Cout] for the data gradient.  Leaf parameters go through the persistent operand
+    cache (one refresh launch per step for all of them); a per-step tensor (the concatenated CenterHead branches) is converted here."""
     kind = _DGRAD_KIND[param_kind] if dgrad else param_kind
-
-    def make():
+    if not param.is_leaf:
         src = param.detach()
         return K.weight_layout_split(src if src.is_contiguous() else src.contiguous(), Cout, Cin, taps, kind, False)
-    if not param.is_leaf:
-        return make()
-    key = (id(param), "op", kind)
-    ver = (param._version, _WEIGHTS_EPOCH[0] if param.requires_grad else -1, param.data_ptr(), Cout, Cin, taps)
-    hit = _SPLIT_W_CACHE.get(key)
-    if hit is not None and hit[0] == ver and hit[2]() is param:
-        return hit[1]
-    w = make()
-    _SPLIT_W_CACHE[key] = (ver, w, weakref.ref(param))
-    return w
+    return _OPERANDS.get(param, Cout, Cin, taps, kind)
 
 
 def split_activation(x):

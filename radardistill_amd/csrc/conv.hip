@@ -701,6 +701,36 @@ extern "C" int rd_weight_layout_split(const float *src, void *dst, int Cout, int
     return check_launch("rd_weight_layout_split");
 }
 
+// Many weights in ONE launch (the per-step refresh of every trainable conv weight's GEMM operands): block c converts 256 groups of 4
+// destination elements of job chunk_job[c], starting at group chunk_group[c].
+__global__ void k_weight_layout_split_multi(const rd_layout_job *__restrict__ jobs, const int *__restrict__ chunk_job,
+                                            const int *__restrict__ chunk_group) {
+    const rd_layout_job j = jobs[chunk_job[blockIdx.x]];
+    const int64_t g = (int64_t)chunk_group[blockIdx.x] + threadIdx.x;
+    if (g * 4 >= (int64_t)j.Cout * j.Cin * j.taps) return;
+    unsigned short hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float v = j.src[layout_src(g * 4 + e, j.Cout, j.Cin, j.taps, j.kind, 0)];
+        const __bf16 h = (__bf16)v;
+        const __bf16 l = (__bf16)(v - (float)h);
+        hi[e] = __builtin_bit_cast(unsigned short, h);
+        lo[e] = __builtin_bit_cast(unsigned short, l);
+    }
+    uint2 *dst = reinterpret_cast<uint2 *>(j.dst);
+    dst[2 * g] = make_uint2(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16));
+    dst[2 * g + 1] = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
+}
+
+extern "C" int rd_weight_layout_split_multi(const rd_layout_job *jobs_dev, const int *chunk_job_dev, const int *chunk_group_dev, int n_chunks,
+                                            void *stream) {
+    RD_REQUIRE(n_chunks >= 0, "rd_weight_layout_split_multi: bad chunk count");
+    if (n_chunks == 0) return RD_OK;
+    RD_REQUIRE(jobs_dev && chunk_job_dev && chunk_group_dev, "rd_weight_layout_split_multi: null table");
+    k_weight_layout_split_multi<<<n_chunks, 256, 0, S(stream)>>>(jobs_dev, chunk_job_dev, chunk_group_dev);
+    return check_launch("rd_weight_layout_split_multi");
+}
+
 extern "C" int rd_weight_layout(const float *src, float *dst, int Cout, int Cin, int taps, int kind, int flip, void *stream) {
     RD_REQUIRE(kind >= 0 && kind <= 8, "rd_weight_layout: bad kind %d", kind);
     int64_t total = (int64_t)Cout * Cin * taps;

@@ -5,6 +5,7 @@ whole GPU host), passes raw device pointers plus the current HIP stream, and rai
 non-zero return code.  No function here has a CPU path.
 """
 import ctypes
+import os
 
 import torch
 
@@ -177,14 +178,40 @@ def split_bf16(x):
     return out
 
 
-def weight_layout_split(src, Cout, Cin, taps, kind, flip=False):
-    """Like weight_layout (operand kinds 0..3, 7, 8) with the destination written in split format."""
+def weight_layout_split(src, Cout, Cin, taps, kind, flip=False, out=None):
+    """Like weight_layout (operand kinds 0..3, 7, 8) with the destination written in split format (into `out` if given)."""
     _chk(src, f32, "weight")
     if src.numel() != Cout * Cin * taps:
         raise RuntimeError("weight_layout_split: element count mismatch")
-    dst = torch.empty(Cout * Cin * taps, dtype=f32, device=src.device)
-    check(native.lib().rd_weight_layout_split(_p(src), _p(dst), Cout, Cin, taps, kind, int(flip), _stream()), "rd_weight_layout_split")
-    return dst
+    if out is None:
+        out = torch.empty(Cout * Cin * taps, dtype=f32, device=src.device)
+    elif _chk(out, f32, "split destination").numel() != Cout * Cin * taps:
+        raise RuntimeError("weight_layout_split: destination size mismatch")
+    check(native.lib().rd_weight_layout_split(_p(src), _p(out), Cout, Cin, taps, kind, int(flip), _stream()), "rd_weight_layout_split")
+    return out
+
+
+def weight_layout_split_multi(jobs_dev, chunk_job_dev, chunk_group_dev, n_chunks):
+    """One launch for a table of rd_layout_job entries (device copies of the job array and the chunk tables; autograd._OperandCache)."""
+    if not (jobs_dev.is_cuda and jobs_dev.dtype == torch.uint8 and jobs_dev.is_contiguous()):
+        raise RuntimeError("weight_layout_split_multi: job table must be a contiguous CUDA uint8 tensor")
+    _chk(chunk_job_dev, i32, "chunk_job", 1); _chk(chunk_group_dev, i32, "chunk_group", 1)
+    if chunk_job_dev.numel() != n_chunks or chunk_group_dev.numel() != n_chunks:
+        raise RuntimeError("weight_layout_split_multi: chunk tables must have n_chunks entries")
+    check(native.lib().rd_weight_layout_split_multi(_p(jobs_dev), _p(chunk_job_dev), _p(chunk_group_dev), int(n_chunks), _stream()),
+          "rd_weight_layout_split_multi")
+
+
+def _kernel_tag(ix, in_rows, out_rows, Cin, Cout, taps, in_split, tile):
+    """Which instantiation rd_conv_fwd launches (mirrors the dispatch in conv.hip / conv_b3.hip; used by bench.py's roofline only):
+    128 / 64 = gathered implicit-GEMM tile, "d3_128" / "d3_64" = halo-staged dense 3x3 kernel (bf16x3 mode)."""
+    if (get_conv_math() == "bf16x3" and ix.mode in (1, 2) and taps == 9 and ix.KH == 3 and ix.KW == 3 and ix.stride == 1 and ix.pad == 1
+            and ix.Hin == ix.Hout and ix.Win == ix.Wout and Cin % 32 == 0 and not in_split and in_rows == out_rows
+            and os.environ.get("RD_D3", "1") != "0"):
+        nb = out_rows // (ix.Hout * ix.Wout)
+        big = nb * ((ix.Hout + 7) // 8) * ((ix.Wout + 15) // 16) * ((Cout + 127) // 128)
+        return "d3_128" if big >= 384 else "d3_64"
+    return tile
 
 
 def conv_fwd(x, weight_k, taps, bias, out_rows, Cout, ix, scale=None, shift=None, residual=None, relu=False, stats=None, nbr_keepalive=None,
@@ -208,6 +235,8 @@ def conv_fwd(x, weight_k, taps, bias, out_rows, Cout, ix, scale=None, shift=None
     # every launch of the Cout > 64, non-deform instantiations; `tile` mirrors the selection rule of rd_conv_fwd (conv.hip)
     prof = CONV_PROFILE is not None and Cout > 64 and ix.mode != 3
     tile = 128 if ((out_rows + 127) // 128) * ((Cout + 127) // 128) >= 384 else 64
+    if prof:
+        tile = _kernel_tag(ix, in_rows, out_rows, Cin, Cout, taps, in_split, tile)
     if prof:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()

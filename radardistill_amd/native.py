@@ -24,6 +24,11 @@ class ConvIndex(ctypes.Structure):
                 ("samp_idx", c_vp), ("samp_w", c_vp)]
 
 
+class LayoutJob(ctypes.Structure):
+    """rd_layout_job of include/rdamd.h."""
+    _fields_ = [("src", c_vp), ("dst", c_vp), ("Cout", c_int), ("Cin", c_int), ("taps", c_int), ("kind", c_int)]
+
+
 class TargetCfg(ctypes.Structure):
     """rd_target_cfg of include/rdamd.h."""
     _fields_ = [("n_classes", c_int), ("n_heads", c_int), ("n_channels", c_int), ("head_of_class", c_int * 16),
@@ -55,6 +60,7 @@ SIGNATURES = {
     "rd_get_conv_math": (c_int, []),
     "rd_split_bf16": (c_int, [_P, c_i64, _P, _P]),
     "rd_weight_layout_split": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "rd_weight_layout_split_multi": (c_int, [_P, _P, _P, c_int, _P]),
     "rd_conv_fwd_split": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, c_int, c_int, ctypes.POINTER(ConvIndex), _P, _P, _P, c_int, _P, _P]),
     "rd_conv_wgrad_split": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, ctypes.POINTER(ConvIndex), _P, _P]),
     "rd_conv_dgrad": (c_int, [_P, c_int, c_int, _P, c_int, _P, c_int, c_int, ctypes.POINTER(ConvIndex), _P]),

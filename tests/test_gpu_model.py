@@ -405,6 +405,40 @@ def test_bf16x3_conv_math_parity(golden_dir):
         K.set_conv_math("f32")
 
 
+def test_operand_cache_multi_refresh_matches_single_conversions():
+    """autograd._OperandCache: the one-launch refresh of every stale weight operand (rd_weight_layout_split_multi) writes exactly
+    what the per-weight conversion writes, for every operand kind, after torch-side updates and after the fused optimizer's epoch bump."""
+    from radardistill_amd import autograd as A, kernels as K
+    g = torch.Generator(device="cpu").manual_seed(4)
+    shapes = [((96, 3, 3, 64), 0, 96, 64, 9), ((128, 64, 3, 3), 1, 128, 64, 9), ((64, 128, 2, 2), 3, 128, 64, 4), ((256, 1024), 0, 256, 1024, 1)]
+    params = [torch.nn.Parameter(torch.randn(*sh, generator=g).to(DEV)) for sh, _, _, _, _ in shapes]
+    cache = A._OperandCache()
+
+    def check_all():
+        for p_, (_, pk, Cout, Cin, taps) in zip(params, shapes):
+            for dgrad in (False, True):
+                kind = A._DGRAD_KIND[pk] if dgrad else pk
+                got = cache.get(p_, Cout, Cin, taps, kind)
+                want = K.weight_layout_split(p_.detach().contiguous(), Cout, Cin, taps, kind, False)
+                assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (pk, dgrad)
+
+    check_all()                                              # entries created one by one
+    with torch.no_grad():
+        for p_ in params:
+            p_.mul_(1.5)                                     # torch-side update: _version bump
+    cache.refresh_all(torch.device(DEV))
+    assert cache.table is not None and cache.table[4] > 0
+    ptrs = {k: e[1].data_ptr() for k, e in cache.entries.items()}
+    assert all(e[0] == cache._ver(e[2]()) for e in cache.entries.values())      # nothing left stale -> check_all converts nothing itself
+    check_all()
+    for p_ in params:                                        # raw-pointer update as the fused optimizer does it, then the epoch bump
+        p_.data.add_(0.25)
+    A.bump_weights_epoch()
+    cache.refresh_all(torch.device(DEV))
+    assert {k: e[1].data_ptr() for k, e in cache.entries.items()} == ptrs       # persistent destination buffers
+    check_all()
+
+
 def test_stream_overlaps_do_not_change_gradients():
     """The same training step with every stream feature off (geometry prelude, weight-gradient side stream, teacher stream) and with
     all of them on, once as a single backward pass and once accumulating two passes into .grad: every parameter gradient agrees up
