@@ -375,6 +375,30 @@ int rd_gelu_grn_fwd(const float *z, int B, int64_t hw, int C, const float *gamma
 int rd_gelu_grn_bwd(const float *grad_out, const float *a, const float *z, const float *ssq, int B, int64_t hw, int C, const float *gamma,
                     float *S_ws, float *grad_z, float *grad_gamma, float *grad_beta, void *stream);
 
+/* ---- P. CenterHead training loss, all task heads at once (replaces radar_center_head.py:258-330 get_loss: FocalLossCenterNet
+ * loss_utils.py:169-200, RegLossCenterNet :203-250, per-cell decode :300-314, IouLoss :618-640, IouRegLoss :643-662 with
+ * centernet_utils.bbox3d_overlaps_diou :462-497 and boxes_aligned_iou3d_gpu iou3d_nms_utils.py:83-117).
+ * maps: (B, H, W, NO) fp32 channels-last, column groups [hm | center | center_z | dim | rot | vel | iou], heads inner
+ * (column = base + head * width + j); heatmaps (B, n_ch, H, W); inds / masks (n_heads, B, K) int64; target_boxes (n_heads, B, K, target_dim >= 10);
+ * gt_box (n_heads, B, K, gt_dim >= 7).  fwd: out[4*h + {0,1,2,3}] = hm / loc / iou / iou_reg loss of head h (weights applied as in
+ * the reference: cls_w, loc_w * code_w, 1, 1), out[4*n_heads] = sum_h (hm + loc + iou + loc_w * iou_reg); scale (4*n_heads) and ws
+ * (rd_center_loss_ws_floats floats) carry the normalisers and per-object gradients to bwd, which writes d out[4*n_heads] / d maps
+ * times grad_loss[0] into grad_maps (every element written). */
+typedef struct {
+    int B, H, W, NO, n_heads, n_ch, K;
+    int hm_c0, c0_center, c0_z, c0_dim, c0_rot, c0_vel, c0_iou;
+    int head_of_ch[16];
+    float code_w[10];
+    float cls_w, loc_w;
+    float stride, vs_x, vs_y, org_x, org_y; /* x = ((cell_x + center0) * stride) * vs_x + org_x */
+} rd_center_loss_cfg;
+int64_t rd_center_loss_ws_floats(const rd_center_loss_cfg *cfg);
+int rd_center_loss_fwd(const rd_center_loss_cfg *cfg, const float *maps, const float *heatmaps, const int64_t *inds, const int64_t *masks,
+                       const float *target_boxes, int target_dim, const float *gt_box, int gt_dim, float *out, float *scale, float *ws,
+                       void *stream);
+int rd_center_loss_bwd(const rd_center_loss_cfg *cfg, const float *maps, const float *heatmaps, const int64_t *inds, const int64_t *masks,
+                       const float *scale, const float *ws, const float *grad_loss, float *grad_maps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -743,3 +743,27 @@ class _GeluGRNFn(torch.autograd.Function):
 def gelu_grn(z_rows, grn, B):
     """act = GELU then grn (Basicblock_convn.GRN parameter container) on rows (B*hw, C)."""
     return _GeluGRNFn.apply(z_rows, grn.gamma, grn.beta, B)
+
+
+class _CenterLossFn(torch.autograd.Function):
+    """All CenterHead loss terms of all task heads (centerloss.hip): returns (total loss (1,), per-head [hm, loc, iou, iou_reg] (nh, 4))."""
+
+    @staticmethod
+    def forward(ctx, maps, cfg, heatmaps, inds, masks, target_boxes, gt_box):
+        out, scale, ws = K.center_loss_fwd(cfg, maps, heatmaps, inds, masks, target_boxes, gt_box)
+        ctx.cfg = cfg
+        ctx.save_for_backward(maps, heatmaps, inds, masks, scale, ws)
+        nh = cfg.n_heads
+        per_head = out[:4 * nh].view(nh, 4)
+        ctx.mark_non_differentiable(per_head)
+        return out[4 * nh:], per_head
+
+    @staticmethod
+    def backward(ctx, g_total, _g_per_head):
+        maps, heatmaps, inds, masks, scale, ws = ctx.saved_tensors
+        g = g_total.reshape(1).float().contiguous()
+        return K.center_loss_bwd(ctx.cfg, maps, heatmaps, inds, masks, scale, ws, g), None, None, None, None, None, None
+
+
+def center_loss(maps, cfg, heatmaps, inds, masks, target_boxes, gt_box):
+    return _CenterLossFn.apply(maps, cfg, heatmaps, inds, masks, target_boxes, gt_box)

@@ -762,3 +762,32 @@ def set_conv_math(mode):
 
 def get_conv_math():
     return _CONV_MATH[0]
+
+
+# ------------------------------------------------------------------------------------------ CenterHead loss (all heads, fused)
+def center_loss_fwd(cfg, maps, heatmaps, inds, masks, target_boxes, gt_box):
+    """maps (B, H, W, NO); stacked targets of rd_center_targets.  -> (out (4*nh + 1,), scale (4*nh,), ws) -- see rd_center_loss_fwd."""
+    _chk(maps, f32, "maps", 4); _chk(heatmaps, f32, "heatmaps", 4); _chk(target_boxes, f32, "target_boxes", 4); _chk(gt_box, f32, "gt_box", 4)
+    i64 = torch.int64
+    _chk(inds, i64, "inds", 3); _chk(masks, i64, "masks", 3)
+    nh, B, Kk = cfg.n_heads, cfg.B, cfg.K
+    if tuple(maps.shape) != (B, cfg.H, cfg.W, cfg.NO) or tuple(heatmaps.shape) != (B, cfg.n_ch, cfg.H, cfg.W):
+        raise RuntimeError(f"center_loss: maps {tuple(maps.shape)} / heatmaps {tuple(heatmaps.shape)} do not match the configuration")
+    if tuple(inds.shape) != (nh, B, Kk) or tuple(masks.shape) != (nh, B, Kk) or tuple(target_boxes.shape[:3]) != (nh, B, Kk) or tuple(gt_box.shape[:3]) != (nh, B, Kk):
+        raise RuntimeError("center_loss: target tensors must be (n_heads, B, K, ...)")
+    out = torch.empty(4 * nh + 1, dtype=f32, device=maps.device)
+    scale = torch.empty(4 * nh, dtype=f32, device=maps.device)
+    ws = torch.empty(int(native.lib().rd_center_loss_ws_floats(ctypes.byref(cfg))), dtype=f32, device=maps.device)
+    check(native.lib().rd_center_loss_fwd(ctypes.byref(cfg), _p(maps), _p(heatmaps), _p(inds), _p(masks), _p(target_boxes), target_boxes.shape[3],
+                                          _p(gt_box), gt_box.shape[3], _p(out), _p(scale), _p(ws), _stream()), "rd_center_loss_fwd")
+    return out, scale, ws
+
+
+def center_loss_bwd(cfg, maps, heatmaps, inds, masks, scale, ws, grad_loss):
+    _chk(grad_loss, f32, "grad_loss")
+    if grad_loss.numel() != 1:
+        raise RuntimeError("center_loss_bwd: grad_loss must hold one value")
+    grad = torch.empty_like(maps)
+    check(native.lib().rd_center_loss_bwd(ctypes.byref(cfg), _p(maps), _p(heatmaps), _p(inds), _p(masks), _p(scale), _p(ws), _p(grad_loss), _p(grad),
+                                          _stream()), "rd_center_loss_bwd")
+    return grad

@@ -29,6 +29,14 @@ class LayoutJob(ctypes.Structure):
     _fields_ = [("src", c_vp), ("dst", c_vp), ("Cout", c_int), ("Cin", c_int), ("taps", c_int), ("kind", c_int)]
 
 
+class CenterLossCfg(ctypes.Structure):
+    """rd_center_loss_cfg of include/rdamd.h."""
+    _fields_ = [("B", c_int), ("H", c_int), ("W", c_int), ("NO", c_int), ("n_heads", c_int), ("n_ch", c_int), ("K", c_int),
+                ("hm_c0", c_int), ("c0_center", c_int), ("c0_z", c_int), ("c0_dim", c_int), ("c0_rot", c_int), ("c0_vel", c_int), ("c0_iou", c_int),
+                ("head_of_ch", c_int * 16), ("code_w", c_f32 * 10), ("cls_w", c_f32), ("loc_w", c_f32),
+                ("stride", c_f32), ("vs_x", c_f32), ("vs_y", c_f32), ("org_x", c_f32), ("org_y", c_f32)]
+
+
 class TargetCfg(ctypes.Structure):
     """rd_target_cfg of include/rdamd.h."""
     _fields_ = [("n_classes", c_int), ("n_heads", c_int), ("n_channels", c_int), ("head_of_class", c_int * 16),
@@ -61,6 +69,9 @@ SIGNATURES = {
     "rd_split_bf16": (c_int, [_P, c_i64, _P, _P]),
     "rd_weight_layout_split": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "rd_weight_layout_split_multi": (c_int, [_P, _P, _P, c_int, _P]),
+    "rd_center_loss_ws_floats": (c_i64, [_P]),
+    "rd_center_loss_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, _P, _P, _P, _P]),
+    "rd_center_loss_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "rd_conv_fwd_split": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, c_int, c_int, ctypes.POINTER(ConvIndex), _P, _P, _P, c_int, _P, _P]),
     "rd_conv_wgrad_split": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, ctypes.POINTER(ConvIndex), _P, _P]),
     "rd_conv_dgrad": (c_int, [_P, c_int, c_int, _P, c_int, _P, c_int, c_int, ctypes.POINTER(ConvIndex), _P]),

@@ -362,6 +362,16 @@ class Radar_CenterHead(nn.Module):
         nh = len(pred_dicts)
         dev = st['heatmaps'].device
         tb_dict = {}
+        fused = self._fused_loss(st, lw, nh)
+        if fused is not None:
+            loss, per_head = fused
+            for idx in range(nh):
+                tb_dict['hm_loss_head_%d' % idx] = per_head[idx, 0]
+                tb_dict['loc_loss_head_%d' % idx] = per_head[idx, 1]
+                tb_dict['iou_loss_head_%d' % idx] = per_head[idx, 2]
+                tb_dict['iou_reg_loss_head_%d' % idx] = per_head[idx, 3]
+            tb_dict['rpn_loss'] = loss.detach()
+            return loss, tb_dict
         # ---- focal loss on all heat-map channels at once; per-head normalisation by that head's positives
         nc = [p['hm'].shape[1] for p in pred_dicts]
         head_of_ch = A.const_tensor(("head_of_ch", tuple(nc)), [h for h, c in enumerate(nc) for _ in range(c)], dev, torch.int64)
@@ -435,6 +445,41 @@ class Radar_CenterHead(nn.Module):
             tb_dict['iou_reg_loss_head_%d' % idx] = reg_d[idx]
         tb_dict['rpn_loss'] = loss.detach()
         return loss, tb_dict
+
+    def _fused_loss(self, st, lw, nh):
+        """The whole loss in 3 launches forward / 2 backward (centerloss.hip) when the branches were batched into one
+        (B, H, W, NO) map; None -> the torch expressions below (same values; LOSS_CONFIG.FUSED: False forces them)."""
+        stacked = self.forward_ret_dict.get('pred_stacked', None)
+        if stacked is None or not self.model_cfg.LOSS_CONFIG.get('FUSED', True):
+            return None
+        o4, groups = stacked
+        names = ('center', 'center_z', 'dim', 'rot', 'vel', 'iou')
+        want = {'center': 2, 'center_z': 1, 'dim': 3, 'rot': 2, 'vel': 2, 'iou': 1}
+        if not o4.is_cuda or any(n not in groups for n in names + ('hm',)) or any(list(groups[n][1]) != [want[n]] * nh for n in names):
+            return None
+        nc = list(groups['hm'][1])
+        if nh > 8 or sum(nc) > 16 or len(lw['code_weights']) != 10 or st['target_boxes'].shape[-1] < 10:
+            return None
+        from radardistill_amd.native import CenterLossCfg
+        B, H, W, NO = o4.shape
+        key = (B, H, W, NO, tuple(nc), tuple((n, groups[n][0]) for n in names + ('hm',)), st['inds'].shape[2])
+        cached = getattr(self, '_loss_cfg_cache', None)
+        if cached is None or cached[0] != key:
+            c = CenterLossCfg()
+            c.B, c.H, c.W, c.NO, c.n_heads, c.n_ch, c.K = B, H, W, NO, nh, sum(nc), st['inds'].shape[2]
+            c.hm_c0, c.c0_center, c.c0_z, c.c0_dim = groups['hm'][0], groups['center'][0], groups['center_z'][0], groups['dim'][0]
+            c.c0_rot, c.c0_vel, c.c0_iou = groups['rot'][0], groups['vel'][0], groups['iou'][0]
+            for i, h in enumerate([h for h, n in enumerate(nc) for _ in range(n)]):
+                c.head_of_ch[i] = h
+            for i, w in enumerate(lw['code_weights']):
+                c.code_w[i] = float(w)
+            c.cls_w, c.loc_w = float(lw['cls_weight']), float(lw['loc_weight'])
+            c.stride, c.vs_x, c.vs_y = float(int(self.feature_map_stride)), float(self.voxel_size[0]), float(self.voxel_size[1])
+            c.org_x, c.org_y = float(int(self.point_cloud_range[0])), float(int(self.point_cloud_range[1]))   # the reference's int() truncation
+            cached = self._loss_cfg_cache = (key, c)
+        maps = o4 if o4.is_contiguous() else o4.contiguous()
+        return A.center_loss(maps, cached[1], st['heatmaps'].contiguous(), st['inds'].contiguous(), st['masks'].contiguous(),
+                             st['target_boxes'].contiguous(), st['gt_box'].contiguous())
 
     def get_loss_per_head(self):
         pred_dicts = self.forward_ret_dict['pred_dicts']

@@ -228,6 +228,35 @@ def test_center_head_golden(golden_dir):
         close(v, g["tb_" + k], rtol=1e-3, atol=1e-5, what=k)
 
 
+@pytest.mark.parametrize("n_boxes,seed", [(12, 3), (60, 9), (0, 1)])
+def test_fused_center_loss_matches_torch_expressions(n_boxes, seed):
+    """centerloss.hip (3 launches forward, 2 backward) against the torch expressions of the same module (LOSS_CONFIG.FUSED: False) on the
+    same maps and targets: total, the four per-head terms, and the gradient w.r.t. every map element.  60 boxes on a 16x16 map put
+    several objects into one cell (scatter-add path); 0 boxes is the all-negative case."""
+    g = np.random.default_rng(seed)
+    feat = torch.from_numpy(g.normal(0, 1, size=(2, 256, 16, 16)).astype(np.float32))
+    batch = make_batch(batch_size=2, n_lidar=16, n_radar=16, n_boxes=max(n_boxes, 1), grid=128, seed=seed)
+    gtb = batch["gt_boxes"].copy()
+    if n_boxes == 0:
+        gtb[:] = 0
+    m = _head(seed=15)
+    m.train()
+    m({"radar_spatial_features_2d": _cl(feat), "gt_boxes": torch.from_numpy(gtb).to(DEV), "gt_boxes_host": gtb, "batch_size": 2})
+    o4 = m.forward_ret_dict['pred_stacked'][0]
+    res = {}
+    for fused in (True, False):
+        m.model_cfg.LOSS_CONFIG['FUSED'] = fused
+        loss, tb = m.get_loss()
+        (go,) = torch.autograd.grad(loss.sum(), o4, retain_graph=True)
+        res[fused] = (loss.detach(), {k: v.detach() for k, v in tb.items()}, go)
+    close(res[True][0], res[False][0], rtol=1e-5, atol=1e-6, what="total")
+    for k, v in res[False][1].items():
+        close(res[True][1][k], v, rtol=1e-5, atol=1e-6, what=k)
+    a, b = res[True][2], res[False][2]
+    assert float((a - b).norm()) <= 1e-5 * float(b.norm()) + 1e-9, (float((a - b).norm()), float(b.norm()))
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-3, atol=1e-6 * float(b.abs().max()))
+
+
 @pytest.mark.parametrize("training", [True, False])
 def test_center_head_batched_branches_equal_per_branch_path(training):
     """The MI355X execution plan (all 42 branches: one conv + one BatchNorm + one narrow-conv launch) against the reference-shaped

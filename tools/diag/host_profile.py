@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--stacks", type=int, default=1)
     args = ap.parse_args()
     device = torch.device("cuda", 0)
+    from radardistill_amd import kernels as K
+    K.set_conv_math(os.environ.get("RD_MATH", "bf16x3"))
     from radardistill_amd.pcdet.models import model_fn_decorator
     from radardistill_amd.synthetic import make_batch
     from radardistill_amd.train import build_optimizer, build_scheduler
