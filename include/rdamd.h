@@ -281,7 +281,8 @@ int rd_adam_step(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, in
 /* ------------------------------------------------------------------------------------------------
  * J. Depthwise KxK convolution on channels-last maps (ConvNeXt dwconv 7x7, groups = C, padding K/2).  Replaces cuDNN's
  *    depthwise conv2d in pcdet/ops/basicblock/modules/Basicblock_convn.py:13,47.  weight_tc is [K*K][C] (tap-major);
- *    flip = 1 reads taps reversed (data gradient).  rd_dwconv_wgrad -> grad in the same [K*K][C] layout.
+ *    flip = 1 reads taps reversed (data gradient).  rd_dwconv_wgrad -> grad in the same [K*K][C] layout (pixel chunks are
+ *    combined with atomics; ws / ws_bytes are unused since ABI 1 and may be NULL / 0, rd_dwconv_wgrad_ws_bytes returns 0).
  * ---------------------------------------------------------------------------------------------- */
 int rd_dwconv_fwd(const float *in, const float *weight_tc, const float *bias, int B, int H, int W, int C, int K, int flip, float *out,
                   void *stream);

@@ -88,7 +88,7 @@ extern "C" int rd_dcn_prep(const float *offset, int off_stride, const float *mas
     return check_launch("rd_dcn_prep");
 }
 
-// One wave per (output pixel j, tap t); lanes sweep the C channels 4 at a time (C % 256 == 0 -> C/256 float4 per lane).
+// One wave per (output pixel j, tap t); lanes sweep the C channels, lane l taking l, l + 64, ...
 __global__ __launch_bounds__(256) void k_dcn_bwd_data(const float *__restrict__ x, int C, const float *__restrict__ colgrad,
                                                       const float *__restrict__ offset, int off_stride, const float *__restrict__ mask,
                                                       int mask_stride, int sig, DcnGeom g, int n_rows, int taps, float *grad_x,
@@ -105,32 +105,22 @@ __global__ __launch_bounds__(256) void k_dcn_bwd_data(const float *__restrict__ 
     if (s.inside) {
         const float hh = 1.f - s.lh, hw = 1.f - s.lw;
         const float *gc = colgrad + ((int64_t)j * taps + t) * C;
-        for (int c = lane * 4; c < C; c += 256) {
-            const f32x4 gv = *reinterpret_cast<const f32x4 *>(gc + c);
-            f32x4 v[4];
+        // lane l handles channels l, l + 64, ...: every atomic instruction of the wave covers 256 CONTIGUOUS bytes (the memory-side
+        // float atomics run ~4x slower when a wave's addresses are strided, which the float4-per-lane layout of round 1 made them)
+        for (int c = lane; c < C; c += 64) {
+            const float gv = gc[c];
+            float v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (s.idx[k] >= 0) v[k] = *reinterpret_cast<const f32x4 *>(x + (int64_t)s.idx[k] * C + c);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float val = s.w[0] * v[0][e] + s.w[1] * v[1][e] + s.w[2] * v[2][e] + s.w[3] * v[3][e];
-                dmask += gv[e] * val;
-                // mdmcn_get_coordinate_weight (modulated_deform_im2col_cuda.cuh:84-125)
-                dh += gv[e] * (-hw * v[0][e] - s.lw * v[1][e] + hw * v[2][e] + s.lw * v[3][e]);
-                dw += gv[e] * (-hh * v[0][e] + hh * v[1][e] - s.lh * v[2][e] + s.lh * v[3][e]);
-            }
+            for (int k = 0; k < 4; ++k) v[k] = s.idx[k] >= 0 ? x[(int64_t)s.idx[k] * C + c] : 0.f;
+            const float val = s.w[0] * v[0] + s.w[1] * v[1] + s.w[2] * v[2] + s.w[3] * v[3];
+            dmask += gv * val;
+            // mdmcn_get_coordinate_weight (modulated_deform_im2col_cuda.cuh:84-125)
+            dh += gv * (-hw * v[0] - s.lw * v[1] + hw * v[2] + s.lw * v[3]);
+            dw += gv * (-hh * v[0] + hh * v[1] - s.lh * v[2] + s.lh * v[3]);
             // input gradient: grad_x[corner] += mask * corner weight * column gradient  (col2im, :196-254)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (s.idx[k] >= 0) {
-                    float *dst = grad_x + (int64_t)s.idx[k] * C + c;
-                    const float wk = m * s.w[k];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) atomicAdd(dst + e, wk * gv[e]);
-                }
-            }
+            for (int k = 0; k < 4; ++k)
+                if (s.idx[k] >= 0) atomicAdd(grad_x + (int64_t)s.idx[k] * C + c, m * s.w[k] * gv);
         }
     }
 #pragma unroll

@@ -63,18 +63,12 @@ __global__ __launch_bounds__(256) void k_dwconv_wgrad(const float *__restrict__ 
         __syncthreads();
         if (threadIdx.x < 256 && cg + (int)threadIdx.x < C) {
             const int cc = threadIdx.x;
-            partial[((int64_t)blockIdx.x * gridDim.y + t) * C + cg + cc] = red[0][cc] + red[1][cc] + red[2][cc] + red[3][cc];
+            // pixel chunks combine with fp32 atomics into the zero-filled [tap][C] result: a wave adds 64 contiguous floats (the
+            // separate chunk-sum pass this replaces took 86 us for 12544 outputs, longer than the products themselves)
+            atomicAdd(&partial[(int64_t)t * C + cg + cc], red[0][cc] + red[1][cc] + red[2][cc] + red[3][cc]);
         }
         __syncthreads();
     }
-}
-
-__global__ void k_dw_wsum(const float *__restrict__ partial, int n_chunks, int TC, float *__restrict__ out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= TC) return;
-    double s = 0.0;
-    for (int k = 0; k < n_chunks; ++k) s += (double)partial[(int64_t)k * TC + i];
-    out[i] = (float)s;
 }
 
 extern "C" int rd_dwconv_fwd(const float *in, const float *weight_tc, const float *bias, int B, int H, int W, int C, int K, int flip, float *out,
@@ -86,21 +80,20 @@ extern "C" int rd_dwconv_fwd(const float *in, const float *weight_tc, const floa
 }
 
 extern "C" int64_t rd_dwconv_wgrad_ws_bytes(int B, int H, int W, int C, int K) {
-    int64_t n_pix = (int64_t)B * H * W;
-    int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(64, cdiv(n_pix, 64)));
-    return chunks * K * K * C * 4;
+    (void)B; (void)H; (void)W; (void)C; (void)K;
+    return 0;   // kept for ABI stability: the chunk partials are combined with atomics, no workspace
 }
 
 extern "C" int rd_dwconv_wgrad(const float *in, const float *grad_out, int B, int H, int W, int C, int K, float *grad_w_tc, float *ws,
                                int64_t ws_bytes, void *stream) {
+    (void)ws; (void)ws_bytes;
     RD_REQUIRE(C % 4 == 0 && K % 2 == 1 && K <= 11, "rd_dwconv_wgrad: bad sizes");
     int64_t n_pix = (int64_t)B * H * W;
     int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(64, cdiv(n_pix, 64)));
-    RD_REQUIRE(ws_bytes >= chunks * K * K * C * 4, "rd_dwconv_wgrad: workspace too small");
     int ppc = (int)cdiv(n_pix, chunks);
     hipStream_t st = S(stream);
+    RD_HIP(hipMemsetAsync(grad_w_tc, 0, (size_t)K * K * C * 4, st));
     dim3 grid((unsigned)chunks, (unsigned)(K * K));
-    k_dwconv_wgrad<<<grid, 256, 0, st>>>(in, grad_out, B, H, W, C, K, ppc, ws);
-    k_dw_wsum<<<cdiv(K * K * C, 256), 256, 0, st>>>(ws, (int)chunks, K * K * C, grad_w_tc);
+    k_dwconv_wgrad<<<grid, 256, 0, st>>>(in, grad_out, B, H, W, C, K, ppc, grad_w_tc);
     return check_launch("rd_dwconv_wgrad");
 }

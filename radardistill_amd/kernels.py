@@ -563,10 +563,8 @@ def dwconv_wgrad(x_rows, go_rows, B, H, W, K):
     C = x_rows.shape[1]
     if x_rows.shape != go_rows.shape or x_rows.shape[0] != B * H * W:
         raise RuntimeError("dwconv_wgrad: shape mismatch")
-    nb = native.lib().rd_dwconv_wgrad_ws_bytes(B, H, W, C, K)
-    ws = torch.empty(nb // 4, dtype=f32, device=x_rows.device)
     gw = torch.empty((K * K, C), dtype=f32, device=x_rows.device)
-    check(native.lib().rd_dwconv_wgrad(_p(x_rows), _p(go_rows), B, H, W, C, K, _p(gw), _p(ws), nb, _stream()), "rd_dwconv_wgrad")
+    check(native.lib().rd_dwconv_wgrad(_p(x_rows), _p(go_rows), B, H, W, C, K, _p(gw), None, 0, _stream()), "rd_dwconv_wgrad")
     return gw
 
 
