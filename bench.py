@@ -143,7 +143,6 @@ def main():
     def step(it):
         t0 = time.perf_counter()
         sched.step(it)
-        run_model.train()
         optimizer.zero_grad()
         loss, tb, _ = model_func(run_model, dict(batches[it % len(batches)]))
         t1 = time.perf_counter()
@@ -153,6 +152,10 @@ def main():
         host_t.append((t1 - t0, t2 - t1, time.perf_counter() - t2))
         return loss
 
+    run_model.train()            # once, as train_one_epoch does (tools/train_utils/train_utils.py): the recursive mode switch costs ~1.5 ms
+    main_prio = int(os.environ.get("RD_MAIN_PRIO", "0"))
+    if main_prio:
+        torch.cuda.set_stream(torch.cuda.Stream(device, priority=main_prio))
     for it in range(args.warmup):
         step(it)
 
@@ -160,8 +163,11 @@ def main():
         D.barrier()
         torch.cuda.synchronize()
 
+    K.prefill_event_pool(min(30000, 900 * (args.steps + 3)))       # timing events created (and their HIP handles) outside the timed region
     K.CONV_PROFILE = []
     K.BN_PROFILE = []
+    if os.environ.get("RD_BENCH_NO_HOOKS"):          # diagnostic: cost of the per-launch HIP events themselves
+        K.CONV_PROFILE = K.BN_PROFILE = None
     K.WGRAD_PROFILE = [] if os.environ.get("RD_BENCH_SHAPES") else None
     barrier()
     t0 = time.perf_counter()
@@ -169,8 +175,8 @@ def main():
         loss = step(it)
     barrier()
     dt = time.perf_counter() - t0
-    prof, K.CONV_PROFILE = K.CONV_PROFILE, None
-    bnprof, K.BN_PROFILE = K.BN_PROFILE, None
+    prof, K.CONV_PROFILE = (K.CONV_PROFILE or []), None
+    bnprof, K.BN_PROFILE = (K.BN_PROFILE or []), None
     wprof, K.WGRAD_PROFILE = K.WGRAD_PROFILE, None
     last_loss = float(loss.detach())
     # The timed steps overlap the teacher's kernels (side stream) with the student's, so a launch's event-to-event duration includes

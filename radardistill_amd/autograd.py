@@ -300,7 +300,7 @@ def _wgrad_stream(device):
         return None
     s = _WGRAD_STREAMS.get(device)
     if s is None:
-        s = _WGRAD_STREAMS[device] = torch.cuda.Stream(device)
+        s = _WGRAD_STREAMS[device] = torch.cuda.Stream(device, priority=int(os.environ.get("RD_WGRAD_PRIO", "0")))
     return s
 
 

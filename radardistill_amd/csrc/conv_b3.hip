@@ -129,9 +129,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
     f32x4 sw[DEFORM ? AP : 1];
     int cur_tap = -1, tap_iter_mask = tapmask;
 
-    auto load_tile = [&](int s, Regs &R) {
-        const int kc = (s % kchunks) * KB3;
-        if (s % kchunks == 0) {
+    int next_kq = 0;                             // K chunk of the next tile to fetch (tiles are fetched strictly in order:
+    auto load_tile = [&](int, Regs &R) {         // a counter instead of s % kchunks, which costs ~50 VALU instructions per step)
+        const int kc = next_kq * KB3;
+        const bool new_tap = next_kq == 0;
+        if (++next_kq == kchunks) next_kq = 0;
+        if (new_tap) {
             cur_tap = __ffs(tap_iter_mask) - 1;
             tap_iter_mask &= tap_iter_mask - 1;
             if constexpr (DEFORM) {

@@ -57,7 +57,7 @@ class PillarNet(Detector3DTemplate):
                 if fork and prepared:
                     if not forked:
                         if getattr(self, '_teacher_stream', None) is None:
-                            self._teacher_stream = torch.cuda.Stream(dev)
+                            self._teacher_stream = torch.cuda.Stream(dev, priority=int(os.environ.get('RD_TEACHER_PRIO', '0')))
                         side = self._teacher_stream
                         side.wait_stream(main)          # inputs, rulebooks (and last step's readers of recycled teacher memory) are done
                         forked = True
@@ -117,7 +117,7 @@ class PillarNet(Detector3DTemplate):
         # tensors allocated on the geometry stream are read on the main / teacher streams: tell the caching allocator
         streams = [main]
         if getattr(self, '_teacher_stream', None) is None and self.no_grad_module:
-            self._teacher_stream = torch.cuda.Stream(dev)
+            self._teacher_stream = torch.cuda.Stream(dev, priority=int(os.environ.get('RD_TEACHER_PRIO', '0')))
         if getattr(self, '_teacher_stream', None) is not None:
             streams.append(self._teacher_stream)
         for v, (st, _), lvl in zip(vfes, begun, levels):
