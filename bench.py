@@ -181,17 +181,19 @@ def main():
     last_loss = float(loss.detach())
     # The timed steps overlap the teacher's kernels (side stream) with the student's, so a launch's event-to-event duration includes
     # time shared with the other stream.  Two extra steps with the overlap switched off give the kernel's isolated duration.
-    iso_prof = None
+    iso_prof = iso_bn = None
     from radardistill_amd import autograd as A
     if os.environ.get("RD_TEACHER_STREAM", "1") != "0" or A.WGRAD_STREAM[0]:
         prev_env, prev_w = os.environ.get("RD_TEACHER_STREAM", "1"), A.WGRAD_STREAM[0]
         os.environ["RD_TEACHER_STREAM"] = "0"
         A.WGRAD_STREAM[0] = False
         K.CONV_PROFILE = []
+        K.BN_PROFILE = []
         for it in range(args.warmup + args.steps, args.warmup + args.steps + 2):
             step(it)
         torch.cuda.synchronize()
         iso_prof, K.CONV_PROFILE = K.CONV_PROFILE, None
+        iso_bn, K.BN_PROFILE = K.BN_PROFILE, None
         os.environ["RD_TEACHER_STREAM"] = prev_env
         A.WGRAD_STREAM[0] = prev_w
     # the same step in the other arithmetic mode, for reference (outside the timed region)
@@ -316,6 +318,12 @@ def main():
                                    "traffic": None, "launches_per_step": len(big) // max(prof_steps, 1),
                                    "avg_launch_ms": round(ms_tot / len(big), 4), "algorithmic_bytes_per_launch": int(by_tot / len(big)),
                                    "measured": "HIP events around every such launch inside the timed region (other streams' kernels run concurrently)"}
+            ibig = [(a.elapsed_time(b), by) for a, b, by, _ in (iso_bn or []) if by >= 16e6]
+            if ibig:
+                igbs = sum(b for _, b in ibig) / (sum(t for t, _ in ibig) * 1e-3) / 1e9
+                out["roofline_hbm"]["isolated"] = {"achieved": round(igbs, 1), "frac": round(igbs / PEAK_HBM_GBS, 4),
+                                                   "avg_launch_ms": round(sum(t for t, _ in ibig) / len(ibig), 4),
+                                                   "note": "same launches in the 2 extra steps with the stream overlaps off"}
         if other is not None:
             out["other_math"] = other
         if world == 1 and not args.no_cpu_baseline:

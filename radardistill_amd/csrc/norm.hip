@@ -2,6 +2,7 @@
 // sparse <-> dense row scatter.  See include/rdamd.h sections D and E.  All kernels are HBM-bound streaming passes:
 // float4 per lane, consecutive lanes on consecutive channels of a row (rows are contiguous, so a wave covers 1 KiB).
 // Column reductions are one launch: per-block partial sums combined with fp32 atomics (see k_colreduce).
+#include <stdlib.h>
 #include "common.hpp"
 
 using namespace rd;
@@ -186,21 +187,49 @@ __global__ __launch_bounds__(256) void k_bn_train_fwd(const float *__restrict__ 
         }
     }
     __syncthreads();
+    // streaming part: 4 independent float4 per thread and iteration (all loads issued before the first use: the kernel is a pure
+    // HBM stream, so bytes in flight per CU are what sets its rate), channel index advanced incrementally instead of a 64-bit
+    // modulo per element
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        const int c = (int)((i * 4) % C);
-        const f32x4 xv = reinterpret_cast<const f32x4 *>(x)[i];
-        const f32x4 sc4 = *reinterpret_cast<const f32x4 *>(sc_sh + c), sh4 = *reinterpret_cast<const f32x4 *>(sc_sh + C + c);
+    const int dc = (int)((stride * 4) % C);
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int c = (int)((i * 4) % C);
+    const f32x4 *x4 = reinterpret_cast<const f32x4 *>(x), *r4 = reinterpret_cast<const f32x4 *>(residual);
+    f32x4 *y4 = reinterpret_cast<f32x4 *>(y);
+    auto finish = [&](f32x4 xv, f32x4 rv, int cc) {
+        const f32x4 sc4 = *reinterpret_cast<const f32x4 *>(sc_sh + cc), sh4 = *reinterpret_cast<const f32x4 *>(sc_sh + C + cc);
         f32x4 v;
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = fmaf(xv[k], sc4[k], sh4[k]);   // the backward pass re-derives the ReLU mask with this exact expression
-        if (residual) v += reinterpret_cast<const f32x4 *>(residual)[i];
+        if (residual) v += rv;
         if (act == 1) {
+#pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
         } else if (act == 2) {
+#pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = gelu_f(v[k]);
         }
-        reinterpret_cast<f32x4 *>(y)[i] = v;
+        return v;
+    };
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        f32x4 xv[4], rv[4];
+        int cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            xv[u] = x4[i + u * stride];
+            rv[u] = residual ? r4[i + u * stride] : f32x4{0.f, 0.f, 0.f, 0.f};
+            cc[u] = c;
+            c += dc;
+            if (c >= C) c -= C;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) y4[i + u * stride] = finish(xv[u], rv[u], cc[u]);
+    }
+    for (; i < n4; i += stride) {
+        const f32x4 rv = residual ? r4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        y4[i] = finish(x4[i], rv, c);
+        c += dc;
+        if (c >= C) c -= C;
     }
 }
 
@@ -210,8 +239,12 @@ extern "C" int rd_bn_train_fwd(const float *x, int64_t rows, int C, const float 
     RD_REQUIRE(rows > 0, "rd_bn_train_fwd: BatchNorm over zero rows");
     RD_REQUIRE(C % 4 == 0 && C <= 8192 && act >= 0 && act <= 2, "rd_bn_train_fwd: C=%d must be a multiple of 4 (<= 8192), act in 0..2", C);
     const int64_t n4 = rows * C / 4;
-    // >= 8 float4 per thread, so the per-block scale/shift table (C/256 channels per thread) is amortised
-    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n4, 256 * 8), 2048));
+    // >= 8 float4 per thread amortise the per-block scale/shift table (C/256 channels per thread).  RD_BN_GRID_DIV / RD_BN_GRID_MAX
+    // are tuning knobs: 4..16 float4 per thread and 512..4096 workgroups all measure 3.5-3.65 TB/s on the 57 MB launches (isolated) --
+    // ~16 us per launch, of which ~4-5 us are launch ramp-up and tail, i.e. the stream itself runs at ~5 TB/s
+    static const int gdiv = getenv("RD_BN_GRID_DIV") ? atoi(getenv("RD_BN_GRID_DIV")) : 8;
+    static const int gmax = getenv("RD_BN_GRID_MAX") ? atoi(getenv("RD_BN_GRID_MAX")) : 2048;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n4, 256 * (int64_t)gdiv), gmax));
     k_bn_train_fwd<<<blocks, 256, (size_t)2 * C * 4, S(stream)>>>(x, n4, C, stats, (float)rows, gamma, beta, eps, momentum, running_mean,
                                                                    running_var, residual, act, y, mean, rstd, scale, shift);
     return check_launch("rd_bn_train_fwd");
