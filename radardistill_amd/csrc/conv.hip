@@ -424,6 +424,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const WgradArgs a) {
     // dense geometry: every thread walks its XP rows with (b, oy, ox) cursors advanced by WG_KB rows per step -- the per-row
     // divisions by the map size would otherwise sit in front of every gather of every K step
     const bool dense = a.ix.mode == 1 || a.ix.mode == 2;
+    const int t_ky = dense ? t / max(a.ix.KW, 1) : 0, t_kx = dense ? t - t_ky * a.ix.KW : 0;
     int cb[XP], cy[XP], cx[XP];
     if (dense) {
 #pragma unroll
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const WgradArgs a) {
                 }
             } else {
                 int src = -1;
-                if (j < r_end) src = dense ? src_row_dense(a.ix, cb[p], cy[p], cx[p], t) : src_row_w(a, j, t);
+                if (j < r_end) src = dense ? src_row_dense_k(a.ix, cb[p], cy[p], cx[p], t_ky, t_kx) : src_row_w(a, j, t);
                 if (dense) {  // advance the cursor to this thread's row of the next K step
                     cx[p] += WG_KB;
                     while (cx[p] >= a.ix.Wout) {

@@ -397,6 +397,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_b3(const WgradArgsB3 a) {
 
     // dense geometry: a (b, oy, ox) cursor at this thread's first row of the step, advanced without divisions
     const bool dense = a.ix.mode == 1 || a.ix.mode == 2;
+    const int t_ky = dense ? t / max(a.ix.KW, 1) : 0, t_kx = dense ? t - t_ky * a.ix.KW : 0;
     int cb = 0, cy = 0, cx = 0;
     if (dense) {
         const int j = r_begin + 4 * g;
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_b3(const WgradArgsB3 a) {
                 int src = -1;
                 if (j < r_end) {
                     if (dense) {
-                        src = src_row_dense(a.ix, b, y, x, t);
+                        src = src_row_dense_k(a.ix, b, y, x, t_ky, t_kx);
                     } else {
                         ConvArgs c;
                         c.out_rows = a.out_rows;
@@ -817,10 +818,17 @@ bool launch_conv_d3_b3(const ConvArgs &a, hipStream_t st) {
         if (a.w_split) k_conv_d3_b3<8, 16, 128, true><<<grid, block, 0, st>>>(a, flip);
         else k_conv_d3_b3<8, 16, 128, false><<<grid, block, 0, st>>>(a, flip);
     } else {
+        static const int small = getenv("RD_D3_SMALL") ? atoi(getenv("RD_D3_SMALL")) : 0;     // tuning knob: 1 = 8x16x64, 2 = 8x8x128
         const int64_t rows64 = nb * cdiv(ix.Hout, 8) * cdiv(ix.Wout, 8);
-        const dim3 grid(xcd_grid(rows64, cdiv(a.Cout, 64)));
-        if (a.w_split) k_conv_d3_b3<8, 8, 64, true><<<grid, block, 0, st>>>(a, flip);
-        else k_conv_d3_b3<8, 8, 64, false><<<grid, block, 0, st>>>(a, flip);
+        if (small == 1 && a.w_split) {
+            k_conv_d3_b3<8, 16, 64, true><<<dim3(xcd_grid(big_rows, cdiv(a.Cout, 64))), block, 0, st>>>(a, flip);
+        } else if (small == 2 && a.w_split) {
+            k_conv_d3_b3<8, 8, 128, true><<<dim3(xcd_grid(rows64, cdiv(a.Cout, 128))), block, 0, st>>>(a, flip);
+        } else {
+            const dim3 grid(xcd_grid(rows64, cdiv(a.Cout, 64)));
+            if (a.w_split) k_conv_d3_b3<8, 8, 64, true><<<grid, block, 0, st>>>(a, flip);
+            else k_conv_d3_b3<8, 8, 64, false><<<grid, block, 0, st>>>(a, flip);
+        }
     }
     return true;
 }

@@ -57,8 +57,9 @@ __device__ __forceinline__ int src_row(const ConvArgs &a, int j, int t) {
 
 
 // Dense-geometry source row from output coordinates (no division by the map size): same result as src_row() for modes 1 / 2.
-__device__ __forceinline__ int src_row_dense(const rd_conv_index &ix, int b, int oy, int ox, int t) {
-    const int ky = t / ix.KW, kx = t - ky * ix.KW;
+// (ky, kx) of a tap are block constants in the weight-gradient kernels: callers hoist the division out of their row loops
+// (PMC: k_conv_wgrad_b3 issued 15.8 VALU instructions per MFMA, a quarter of them this division repeated for every row)
+__device__ __forceinline__ int src_row_dense_k(const rd_conv_index &ix, int b, int oy, int ox, int ky, int kx) {
     int iy, ixx;
     if (ix.mode == 1) {
         iy = oy * ix.stride - ix.pad + ky;
@@ -81,6 +82,11 @@ __device__ __forceinline__ int src_row_dense(const rd_conv_index &ix, int b, int
     }
     if (iy < 0 || iy >= ix.Hin || ixx < 0 || ixx >= ix.Win) return -1;
     return (b * ix.Hin + iy) * ix.Win + ixx;
+}
+
+__device__ __forceinline__ int src_row_dense(const rd_conv_index &ix, int b, int oy, int ox, int t) {
+    const int ky = t / ix.KW, kx = t - ky * ix.KW;
+    return src_row_dense_k(ix, b, oy, ox, ky, kx);
 }
 
 // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2), so give every XCD a
