@@ -122,7 +122,7 @@ class PillarNet(Detector3DTemplate):
             streams.append(self._teacher_stream)
         for v, (st, _), lvl in zip(vfes, begun, levels):
             st[0].record_stream(gs)                                     # the points were read on the geometry stream
-            for t in (st[2], *lvl.tensors()):
+            for t in (st[0], st[2], *lvl.tensors()):                    # (st[0] may be a converted copy made on that stream)
                 for s_ in streams:
                     t.record_stream(s_)
 
