@@ -139,15 +139,19 @@ def main():
                                        seed=D.shard_seed(rank, i)), device) for i in range(2)]
 
     host_t = []
+    pending = {}                      # batch dicts whose teacher branch was prefetched during the previous step (PillarNet.prefetch_teacher)
+    raw_model = run_model.module if hasattr(run_model, "module") else run_model
 
     def step(it):
         t0 = time.perf_counter()
         sched.step(it)
         optimizer.zero_grad()
-        loss, tb, _ = model_func(run_model, dict(batches[it % len(batches)]))
+        loss, tb, _ = model_func(run_model, pending.pop(it, None) or dict(batches[it % len(batches)]))
         t1 = time.perf_counter()
         loss.backward()
         t2 = time.perf_counter()
+        # the NEXT batch's teacher forward is enqueued here (every step runs exactly one teacher forward, one student forward + backward)
+        pending[it + 1] = raw_model.prefetch_teacher(dict(batches[(it + 1) % len(batches)]))
         optimizer.step()
         host_t.append((t1 - t0, t2 - t1, time.perf_counter() - t2))
         return loss

@@ -434,6 +434,56 @@ def test_bf16x3_conv_math_parity(golden_dir):
         K.set_conv_math("f32")
 
 
+def test_teacher_prefetch_gives_the_same_step():
+    """PillarNet.prefetch_teacher (teacher branch of the NEXT batch enqueued between backward and optimizer.step) against the plain
+    forward on the same batches: identical loss values and gradients up to atomics noise, over three pipelined steps with two
+    alternating batches; a dict that was not prefetched still takes the plain path."""
+    import os
+    from radardistill_amd.pcdet.models import model_fn_decorator
+    grid, B = 128, 2
+    model, cfg, pc_range, voxel, gs = _build_pillarnet(grid)
+    sd = model.state_dict(); seeded_fill_(sd, seed=77); model.load_state_dict(sd)
+    model = model.to(DEV)
+    model.train()
+    batches = [make_batch(batch_size=B, n_lidar=300, n_radar=700, n_boxes=10, grid=grid, seed=s_) for s_ in (5, 6)]
+    fn = model_fn_decorator()
+    prev = os.environ.get("RD_TEACHER_PREFETCH")
+    os.environ["RD_TEACHER_PREFETCH"] = "1"              # off by default (it measured slower); the mechanism must still be right
+
+    def fresh(i):
+        return {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in batches[i % 2].items()}
+
+    def run(pipelined):
+        out, nxt = [], None
+        for it in range(3):
+            model.zero_grad(set_to_none=True)
+            bd = nxt if (pipelined and nxt is not None) else fresh(it)
+            assert ('_teacher_done' in bd) == (pipelined and it > 0)
+            loss, _, _ = fn(model, bd)
+            loss.backward()
+            if pipelined:
+                nxt = model.prefetch_teacher(fresh(it + 1))
+                assert '_teacher_done' in nxt
+            torch.cuda.synchronize()
+            out.append((float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}))
+        return out
+
+    try:
+        ref, got = run(False), run(True)
+    finally:
+        if prev is None:
+            os.environ.pop("RD_TEACHER_PREFETCH", None)
+        else:
+            os.environ["RD_TEACHER_PREFETCH"] = prev
+    for (lr, gr), (lg, gg) in zip(ref, got):
+        assert abs(lr - lg) <= 1e-4 * abs(lr), (lr, lg)
+        top = max(float(v.norm()) for v in gr.values())
+        for k, r in gr.items():
+            rn = float(r.norm())
+            if rn >= 1e-4 * top:
+                assert float((gg[k] - r).norm()) / rn < 0.3, k
+
+
 def test_operand_cache_multi_refresh_matches_single_conversions():
     """autograd._OperandCache: the one-launch refresh of every stale weight operand (rd_weight_layout_split_multi) writes exactly
     what the per-weight conversion writes, for every operand kind, after torch-side updates and after the fused optimizer's epoch bump."""
