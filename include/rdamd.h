@@ -61,6 +61,10 @@ int rd_rankgrid_from_coords(const int32_t *coords, int n, int batch, int H, int 
 /* SparseConv2d(k3,s2,p1) output set (spconv semantics): out cell (b,oy,ox) active iff an active input lies in its
  * 3x3/stride-2 window.  in_coords (n_in,3).  Builds the output rank grid (Ho = (H-1)/2+1 ...). */
 int rd_rankgrid_downsample(const int32_t *in_coords, int n_in, int batch, int Ho, int Wo, uint32_t *out_rankgrid, void *stream);
+/* Same output set computed from the input RANK GRID instead of a coordinate list (in_xmajor: cell order of the input grid as in
+ * rd_rankgrid_coords): needs no row count from the host, so a whole pyramid can be marked and all level sizes read back at once. */
+int rd_rankgrid_downsample_grid(const uint32_t *in_rankgrid, int batch, int H, int W, int in_xmajor, int Ho, int Wo, uint32_t *out_rankgrid,
+                                void *stream);
 
 /* Neighbour tables.  nbr[n_out][9] int32: row of the input feeding tap t = ky*3+kx of output row j, or -1.
  *   subm   : input == output set; tap reads (y+ky-1, x+kx-1).

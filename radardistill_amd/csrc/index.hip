@@ -243,6 +243,56 @@ extern "C" int rd_rankgrid_downsample(const int32_t *in_coords, int n_in, int ba
     return rankgrid_scan(out_rankgrid, n_cells, st);
 }
 
+// The same output set straight from the INPUT RANK GRID (no coordinate list, hence no row count from the host): a whole pyramid of
+// rank grids can be built with static launch shapes and all its level sizes read back in ONE device->host copy.
+__global__ void k_mark_down_bits(const uint32_t *__restrict__ in_bits, int64_t n_words_in, int H, int W, int xmajor, int Ho, int Wo,
+                                 uint32_t *out_bits) {
+    int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words_in) return;
+    uint32_t word = in_bits[w];
+    while (word) {
+        const int bit = __ffs(word) - 1;
+        word &= word - 1;
+        const int64_t cell = w * 32 + bit;
+        int b, y, x;
+        if (xmajor) {
+            y = (int)(cell % H);
+            x = (int)((cell / H) % W);
+        } else {
+            x = (int)(cell % W);
+            y = (int)((cell / W) % H);
+        }
+        b = (int)(cell / ((int64_t)H * W));
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ny = y + 1 - ky;
+            if (ny < 0 || (ny & 1)) continue;
+            const int oy = ny >> 1;
+            if (oy >= Ho) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int nx = x + 1 - kx;
+                if (nx < 0 || (nx & 1)) continue;
+                const int ox = nx >> 1;
+                if (ox >= Wo) continue;
+                const int64_t c = ((int64_t)b * Ho + oy) * Wo + ox;
+                atomicOr(&out_bits[c >> 5], 1u << (c & 31));
+            }
+        }
+    }
+}
+
+extern "C" int rd_rankgrid_downsample_grid(const uint32_t *in_rankgrid, int batch, int H, int W, int in_xmajor, int Ho, int Wo,
+                                           uint32_t *out_rankgrid, void *stream) {
+    RD_REQUIRE(batch > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "rd_rankgrid_downsample_grid: bad sizes");
+    hipStream_t st = S(stream);
+    const int64_t n_in = rg_words((int64_t)batch * H * W);
+    const int64_t n_cells = (int64_t)batch * Ho * Wo, n_words = rg_words(n_cells);
+    RD_HIP(hipMemsetAsync(out_rankgrid, 0, (2 * n_words + 1) * 4, st));
+    k_mark_down_bits<<<cdiv(n_in, 256), 256, 0, st>>>(in_rankgrid, n_in, H, W, in_xmajor, Ho, Wo, out_rankgrid);
+    return rankgrid_scan(out_rankgrid, n_cells, st);
+}
+
 // ---------------------------------------------------------------------------------------------- neighbour tables
 __global__ void k_nbr_subm(const int32_t *coords, int n, const uint32_t *bits, const uint32_t *prefix, int H, int W, int xmajor, int32_t *nbr) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;

@@ -81,6 +81,16 @@ def rankgrid_downsample(in_coords, batch, Ho, Wo):
     return rg
 
 
+def rankgrid_downsample_grid(in_rg, batch, H, W, in_xmajor, Ho, Wo):
+    """SparseConv2d(k3, s2, p1) output rank grid from the INPUT rank grid (no coordinate list / row count needed)."""
+    _chk(in_rg, i32, "in_rankgrid", 1)
+    if in_rg.numel() * 4 != native.lib().rd_rankgrid_bytes(int(batch * H * W)):
+        raise RuntimeError("rankgrid_downsample_grid: input rank grid does not match (batch, H, W)")
+    rg = rankgrid_alloc(batch * Ho * Wo, in_rg.device)
+    check(native.lib().rd_rankgrid_downsample_grid(_p(in_rg), batch, H, W, int(in_xmajor), Ho, Wo, _p(rg), _stream()), "rd_rankgrid_downsample_grid")
+    return rg
+
+
 def nbr_subm(coords, rg, batch, H, W, xmajor):
     n = coords.shape[0]
     nbr = torch.empty((n, 9), dtype=i32, device=coords.device)

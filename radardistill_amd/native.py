@@ -56,6 +56,7 @@ SIGNATURES = {
     "rd_rankgrid_coords": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     "rd_rankgrid_from_coords": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "rd_rankgrid_downsample": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    "rd_rankgrid_downsample_grid": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "rd_nbr_subm": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "rd_nbr_strided": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "rd_nbr_strided_T": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, _P]),

@@ -83,6 +83,27 @@ class _Level:
             yield from lvl.tensors()
 
 
+def mark_pyramid(rg, xmajor, batch, H, W, n_down):
+    """Rank grids of `n_down` stride-2 levels below the grid `rg`, device only (no host read): [(rg_l, Ho, Wo, count tensor), ...]."""
+    out = []
+    for _ in range(n_down):
+        Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        rg_o = K.rankgrid_downsample_grid(rg, batch, H, W, xmajor, Ho, Wo)
+        out.append((rg_o, Ho, Wo, K.rankgrid_count_tensor(rg_o, batch * Ho * Wo)))
+        rg, xmajor, H, W = rg_o, False, Ho, Wo
+    return out
+
+
+def finish_pyramid(level, marked, counts):
+    """Attach the levels marked by mark_pyramid (sizes now known on the host) below `level`, with all neighbour tables."""
+    level.subm_spec()
+    for (rg_o, _, _, _), n_out in zip(marked, counts):
+        if level._down is None:
+            level.down_finish(rg_o, int(n_out))
+        level = level._down[0]
+        level.subm_spec()
+
+
 def build_pyramids(levels, n_down):
     """SubM tables + `n_down` stride-2 levels below each of `levels`, in lockstep: ONE device->host read per depth for all branches."""
     cur = list(levels)

@@ -31,6 +31,30 @@ def rand_sites(rng, B, H, W, n):
     return np.stack([keys // (H * W), (keys // W) % H, keys % W], axis=1).astype(np.int32)
 
 
+@pytest.mark.parametrize("xmajor", [False, True])
+def test_rankgrid_downsample_from_grid_equals_from_coords(xmajor):
+    """rd_rankgrid_downsample_grid (marks the SparseConv2d(k3, s2, p1) output set from the input rank GRID, no host-side row count)
+    produces the same rank grid, word for word, as rd_rankgrid_downsample on the coordinate list; chained three levels deep."""
+    A, K, SP = _mods()
+    rng = np.random.default_rng(11)
+    B, H, W = 3, 37, 50
+    sites = rand_sites(rng, B, H, W, 900)
+    if xmajor:
+        sites = sites[np.lexsort((sites[:, 1], sites[:, 2], sites[:, 0]))]          # (b, x, y) key order
+    coords = torch.from_numpy(sites).to(DEV)
+    rg = K.rankgrid_from_coords(coords, B, H, W, xmajor)
+    h, w, xm = H, W, xmajor
+    for _ in range(3):
+        ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+        ref = K.rankgrid_downsample(coords, B, ho, wo)
+        got = K.rankgrid_downsample_grid(rg, B, h, w, xm, ho, wo)
+        assert torch.equal(ref, got)
+        n = int(K.rankgrid_count_tensor(got, B * ho * wo))
+        assert n > 0
+        coords = K.rankgrid_coords(got, B, ho, wo, False, n)
+        rg, h, w, xm = got, ho, wo, False
+
+
 def test_library_reports_gfx950():
     from radardistill_amd import native
     assert native.lib().rd_device_ok() == 1
