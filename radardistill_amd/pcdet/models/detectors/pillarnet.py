@@ -96,10 +96,9 @@ class PillarNet(Detector3DTemplate):
         start of the next forward (kernel trace: 3-4 ms of idle gaps per step around the step boundary).  Work per step is unchanged
         -- one teacher forward, one student forward + backward -- only its placement moves.  No-op (the dict is returned untouched)
         when the teacher stream is off, in eval mode, or on the CPU.
-        OFF by default (RD_TEACHER_PREFETCH=1 enables): measured 282 vs 307 samples/s.  The teacher does fill the boundary, but the
-        four count read-backs of the index prelude now happen while the GPU is saturated by the backward pass -- each waits 0.3-0.5 ms
-        for a free wave slot even on the high-priority stream -- and the host, which is the scarcer resource at B = 8, ends up 5 ms
-        slower per step.  It needs a prelude without host round trips (device-side counts with upper-bound allocations) to pay."""
+        OFF by default (RD_TEACHER_PREFETCH=1 enables): measured neutral (308 vs 312 samples/s).  With the earlier four-read index
+        prelude it lost 8 %: the read-backs then happen while the GPU is saturated by the backward pass -- each waited 0.3-0.5 ms for
+        a free wave slot even on the high-priority stream -- and the host is the scarcer resource at B = 8."""
         from radardistill_amd.pcdet.models import load_data_to_gpu
         dev = next(self.parameters()).device
         if not (dev.type == "cuda" and self.training and bool(self.no_grad_module) and self.model_cfg.get('TEACHER_STREAM', True)
