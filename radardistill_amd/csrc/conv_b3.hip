@@ -372,6 +372,10 @@ template <bool DEFORM, int TN>
 __global__ __launch_bounds__(256, 2) void k_conv_wgrad_b3(const WgradArgsB3 a) {
     constexpr int T = 128;                       // Cout tile
     constexpr int NJ = TN / 64;                  // 32-wide MFMA column tiles per wave (wave tile 64 couts x TN/2 cins)
+    // ONE LDS buffer, ONE operand register set: 168 VGPRs and 40 KiB let THREE workgroups share a CU, which is worth more than either
+    // refinement tried on top (PMC: waves parked in s_waitcnt / s_barrier 51 % of the time, matrix pipe busy 12.6 %): a second LDS
+    // buffer (80 KiB dynamic, one barrier per K step) leaves one workgroup per CU and ran 1.7x slower; a second register set (operands
+    // fetched two K steps ahead, 214 VGPRs) leaves two per CU and cost 4 % of the step.
     __shared__ __attribute__((aligned(16))) __bf16 lds[2 * (T + TN) * LDB];   // [G hi][G lo][X hi][X lo], rows of 40 bf16
     __shared__ int s_any;
     __bf16 *Gh = lds, *Gl = Gh + T * LDB, *Xh = Gl + T * LDB, *Xl = Xh + TN * LDB;
