@@ -417,6 +417,13 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, spec, Cout, stats):
+        out = _ConvFn.forward_impl(ctx, x, weight, bias, spec, Cout, stats)
+        ctx.save_for_backward(x, weight)
+        return out
+
+    @staticmethod
+    def forward_impl(ctx, x, weight, bias, spec, Cout, stats):
+        """The convolution launch + what its backward needs on `ctx` (shared with _ConvBNActFn); the caller saves x and weight."""
         Cin = x.shape[1]
         ctx.xs = None
         if _b3_wsplit(Cin, Cout):
@@ -427,7 +434,6 @@ class _ConvFn(torch.autograd.Function):
             ctx.has_bias = bias is not None
             ctx.bias_ref = bias
             ctx.wk = None
-            ctx.save_for_backward(x, weight)
             return out
         wk = kernel_weight(weight, Cout, Cin, spec.taps, spec.param_kind)
         if _b3_presplit(Cin, Cout, spec.fwd_ix.mode):
@@ -440,16 +446,20 @@ class _ConvFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias
         ctx.wk = wk                                # kernel-layout weights of THIS step (the optimizer runs after backward)
-        ctx.save_for_backward(x, weight)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         x, weight = ctx.saved_tensors
+        gx, gw, gb = _ConvFn.backward_impl(ctx, x, weight, grad_out.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                           ctx.needs_input_grad[2])
+        return gx, gw, gb, None, None, None
+
+    @staticmethod
+    def backward_impl(ctx, x, weight, grad_out, need_x, need_w, need_b):
         spec, Cout, Cin = ctx.spec, ctx.Cout, ctx.Cin
-        grad_out = grad_out.contiguous()
         gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
+        if need_x:
             wk = ctx.wk
             use_ws = wk is None and Cout % 32 == 0 and _b3_wsplit(Cout, Cin)
             if wk is None and not use_ws:
@@ -486,11 +496,11 @@ class _ConvFn(torch.autograd.Function):
                     o = torch.nonzero(nb[:, t] >= 0).squeeze(1)
                     ref.index_add_(0, nb[o, t], grad_out[o].double() @ w3[:, t, :])
                 _dbg_report(f"conv dgrad Cin={Cin} Cout={Cout} rows {spec.out_rows}->{spec.in_rows} flip={spec.bwd_ix.flip}", gx.double(), ref)
-        if ctx.needs_input_grad[1]:
+        if need_w:
             gw = param_grad_stream(lambda: _ConvFn._wgrad(ctx, x, weight, grad_out, spec, Cout, Cin), x, grad_out, param=weight)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if ctx.has_bias and need_b:
             gb = param_grad_stream(lambda: K.colsum(grad_out) if Cout % 4 == 0 else grad_out.sum(0), grad_out, param=ctx.bias_ref)
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb
 
     @staticmethod
     def _wgrad(ctx, x, weight, grad_out, spec, Cout, Cin):
@@ -573,6 +583,38 @@ def bn_act_train_tensors(x, gamma, beta, running_mean, running_var, eps, momentu
         raise ValueError("Expected more than 1 value per channel when training")
     _BN_TOUCHED.extend(modules)
     return _BNActFn.apply(x, gamma, beta, None, running_mean, running_var, eps, momentum, act, stats)
+
+
+class _ConvBNActFn(torch.autograd.Function):
+    """conv (+bias) -> train-mode BatchNorm (statistics from the conv epilogue) -> (+residual) -> activation as ONE autograd node:
+    the same four launches as _ConvFn + _BNActFn (forward: conv, BN apply; backward: BN reduce + apply, data gradient, weight
+    gradient), but one Function.apply and one backward node per layer instead of two (~20 us of host time per layer and step)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, spec, Cout, gamma, beta, residual, running_mean, running_var, eps, momentum, act):
+        stats = zeros_stats(2 * Cout, x.device)
+        raw = _ConvFn.forward_impl(ctx, x, weight, bias, spec, Cout, stats)
+        y, mean, rstd, scale, shift = K.bn_train_fwd(raw, stats, gamma, beta, eps, momentum, running_mean, running_var, residual, act)
+        ctx.act, ctx.has_res = act, residual is not None
+        ctx.save_for_backward(x, weight, raw, y, gamma, mean, rstd, scale, shift)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, raw, y, gamma, mean, rstd, scale, shift = ctx.saved_tensors
+        graw, gres, gg, gb_bn = K.bn_bwd(raw, y, gy.contiguous(), gamma, mean, rstd, scale, shift, ctx.act, ctx.has_res)
+        n = ctx.needs_input_grad
+        gx, gw, gb = _ConvFn.backward_impl(ctx, x, weight, graw, n[0], n[1], n[2])
+        return gx, gw, gb, None, None, gg, gb_bn, gres, None, None, None, None, None
+
+
+def conv_bn_act_train(x, weight, bias, spec, Cout, bn, residual=None, act=1):
+    """Training-mode conv -> BatchNorm module `bn` -> (+residual) -> act, one autograd node (see _ConvBNActFn)."""
+    if spec.out_rows <= 1:
+        raise ValueError("Expected more than 1 value per channel when training")     # torch's own train-mode BN error
+    _BN_TOUCHED.append(bn)
+    return _ConvBNActFn.apply(x, weight, bias, spec, Cout, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, float(bn.eps),
+                              float(bn.momentum), act)
 
 
 _BN_FOLD_CACHE = {}

@@ -42,9 +42,7 @@ def conv_bn_act(x, conv, bn=None, residual_rows=None, act=1, return_rows=False, 
         scale, shift = A.bn_eval_scale_shift(bn)
         out = A.conv_inference(rows, conv.weight, conv.bias, spec, Cout, scale, shift, residual_rows, act == 1)
     elif bn.training:
-        stats = A.zeros_stats(2 * Cout, rows.device)
-        raw = A.conv(rows, conv.weight, conv.bias, spec, Cout, stats)
-        out = A.bn_act_train(raw, bn, residual_rows, act=act, stats=stats)
+        out = A.conv_bn_act_train(rows, conv.weight, conv.bias, spec, Cout, bn, residual_rows, act)
     else:
         raw = A.conv(rows, conv.weight, conv.bias, spec, Cout, None)
         out = A.bn_act_eval(raw, bn, residual_rows, act=act)

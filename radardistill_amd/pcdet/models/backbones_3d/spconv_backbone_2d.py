@@ -32,9 +32,7 @@ class _SparseConvBNReLU(spconv.SparseSequential):
             scale, shift = A.bn_eval_scale_shift(bn)
             feats = A.conv_inference(x.features, conv.weight, conv.bias, spec, conv.out_channels, scale, shift, None, True)
         elif bn.training:
-            stats = A.zeros_stats(2 * conv.out_channels, x.features.device)
-            raw = A.conv(x.features, conv.weight, conv.bias, spec, conv.out_channels, stats)
-            feats = A.bn_act_train(raw, bn, None, act=1, stats=stats)
+            feats = A.conv_bn_act_train(x.features, conv.weight, conv.bias, spec, conv.out_channels, bn, None, 1)
         else:
             raw = A.conv(x.features, conv.weight, conv.bias, spec, conv.out_channels, None)
             feats = A.bn_act_eval(raw, bn, None, act=1)
@@ -99,12 +97,8 @@ class SparseBasicBlock(spconv.SparseModule):
             y = A.conv_inference(f, self.conv1.weight, self.conv1.bias, spec, C, s1, h1, None, True)
             y = A.conv_inference(y, self.conv2.weight, self.conv2.bias, spec, C, s2, h2, f, True)
         elif self.bn1.training:
-            st1 = A.zeros_stats(2 * C, f.device)
-            y = A.conv(f, self.conv1.weight, self.conv1.bias, spec, C, st1)
-            y = A.bn_act_train(y, self.bn1, None, act=1, stats=st1)
-            st2 = A.zeros_stats(2 * C, f.device)
-            y = A.conv(y, self.conv2.weight, self.conv2.bias, spec, C, st2)
-            y = A.bn_act_train(y, self.bn2, f, act=1, stats=st2)
+            y = A.conv_bn_act_train(f, self.conv1.weight, self.conv1.bias, spec, C, self.bn1, None, 1)
+            y = A.conv_bn_act_train(y, self.conv2.weight, self.conv2.bias, spec, C, self.bn2, f, 1)
         else:
             y = A.conv(f, self.conv1.weight, self.conv1.bias, spec, C, None)
             y = A.bn_act_eval(y, self.bn1, None, act=1)

@@ -133,7 +133,10 @@ class _BranchBatch:
         training = bns[0].training
         if any(bn.training != training for bn in bns):
             return None
-        params_frozen = not any(p.requires_grad for b in self.branches for m in b[2:5] for p in m.parameters())
+        flags = getattr(self, '_frozen_flag', None)             # walking 126 modules' parameters every step cost 0.6 ms
+        if flags is None or flags[0] is not training:
+            flags = self._frozen_flag = (training, not any(p.requires_grad for b in self.branches for m in b[2:5] for p in m.parameters()))
+        params_frozen = flags[1]
         if (not torch.is_grad_enabled() or (params_frozen and not rows.requires_grad)) and not training:
             w1k, b1, scale, shift, w2, b2 = self._frozen_tensors()
             y = K.conv_fwd(rows, w1k, 9, b1, rows.shape[0], C1, spec.fwd_ix, scale=scale, shift=shift, relu=True)

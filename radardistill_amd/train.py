@@ -84,6 +84,7 @@ class FusedAdamOneCycle:
                            for _ in range(self._ring)]
         self.table_dev = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(self._ring)]
         self._copied = [None] * self._ring
+        self._slot_sig = [None] * self._ring
         self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)
         self.ws = torch.empty(self.n_chunks, dtype=torch.float32, device=dev)
         self._zero = {}
@@ -106,6 +107,22 @@ class FusedAdamOneCycle:
             p.grad = None
 
     def _fill_table(self):
+        # gradient tensors are new objects every step but, in steady state, the allocator hands back the same addresses: when a
+        # ring slot was filled from exactly these pointers its device copy is still valid -- no refill, no host->device copy
+        grads = []
+        for i, p in enumerate(self.params):
+            g = p.grad
+            if g is None:                      # parameter unused this step: zero gradient (Adam still decays its moments)
+                g = self._zero.get(i)
+                if g is None:
+                    g = self._zero[i] = torch.zeros_like(p)
+            elif not g.is_contiguous() or g.dtype != torch.float32:
+                g = p.grad = g.float().contiguous()
+            grads.append(g.data_ptr())
+        sig = (tuple(grads), tuple(p.data_ptr() for p in self.params))
+        for slot in range(self._ring):
+            if self._slot_sig[slot] == sig:
+                return self.table_dev[slot]
         self._slot = (self._slot + 1) % self._ring
         ev = self._copied[self._slot]
         if ev is not None:
@@ -124,17 +141,8 @@ class FusedAdamOneCycle:
             cols[:, 4] = [p.numel() for p in self.params]
             static = self._static_cols = (tuple(int(v) for v in cols[:, 0]), cols)
         tab[:] = static[1]
-        grads = []
-        for i, p in enumerate(self.params):
-            g = p.grad
-            if g is None:                      # parameter unused this step: zero gradient (Adam still decays its moments)
-                g = self._zero.get(i)
-                if g is None:
-                    g = self._zero[i] = torch.zeros_like(p)
-            elif not g.is_contiguous() or g.dtype != torch.float32:
-                g = p.grad = g.float().contiguous()
-            grads.append(g.data_ptr())
         tab[:, 1] = grads
+        self._slot_sig[self._slot] = sig
         dev_t.copy_(host, non_blocking=True)
         if dev_t.is_cuda:
             ev = torch.cuda.Event()
