@@ -31,6 +31,44 @@ def rand_sites(rng, B, H, W, n):
     return np.stack([keys // (H * W), (keys // W) % H, keys % W], axis=1).astype(np.int32)
 
 
+@pytest.mark.parametrize("act,res", [(1, False), (1, True), (2, False)])
+def test_fused_conv_bn_act_node_equals_separate_nodes(act, res):
+    """autograd._ConvBNActFn (conv -> train-mode BatchNorm -> (+residual) -> act as ONE autograd node) against the two separate nodes
+    it replaces (A.conv with fused statistics + A.bn_act_train): same kernels, so outputs, running statistics and every gradient
+    (input, weight, bias, gamma, beta, residual) agree up to the order of the atomics."""
+    A, K, SP = _mods()
+    rng = np.random.default_rng(5 + act + 2 * res)
+    B, H, W, Cin, Cout = 2, 12, 10, 64, 96
+    spec = A.dense_conv_spec(B, H, W, 3, 3, 1, 1)
+    x0 = torch.from_numpy(rng.normal(size=(B * H * W, Cin)).astype(np.float32)).to(DEV)
+    r0 = torch.from_numpy(rng.normal(size=(B * H * W, Cout)).astype(np.float32)).to(DEV) if res else None
+    go = torch.from_numpy(rng.normal(size=(B * H * W, Cout)).astype(np.float32)).to(DEV)
+    conv = torch.nn.Conv2d(Cin, Cout, 3, 1, 1, bias=True).to(DEV)
+    bn = torch.nn.BatchNorm2d(Cout, eps=1e-3, momentum=0.01).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, Cout).astype(np.float32)))
+        bn.bias.copy_(torch.from_numpy(rng.normal(size=Cout).astype(np.float32)))
+    out = {}
+    for fused in (False, True):
+        for p_ in list(conv.parameters()) + list(bn.parameters()):
+            p_.grad = None
+        bn.running_mean.zero_(); bn.running_var.fill_(1.0)
+        x = x0.clone().requires_grad_(True)
+        r = r0.clone().requires_grad_(True) if res else None
+        A.begin_step(torch.device(DEV))
+        if fused:
+            y = A.conv_bn_act_train(x, conv.weight, conv.bias, spec, Cout, bn, r, act)
+        else:
+            st = A.zeros_stats(2 * Cout, x.device)
+            y = A.bn_act_train(A.conv(x, conv.weight, conv.bias, spec, Cout, st), bn, r, act=act, stats=st)
+        (y * go).sum().backward()
+        torch.cuda.synchronize()
+        out[fused] = [y.detach(), x.grad, conv.weight.grad.clone(), conv.bias.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(),
+                      bn.running_mean.clone(), bn.running_var.clone()] + ([r.grad] if res else [])
+    for a, b in zip(out[True], out[False]):
+        close(a, b, rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("xmajor", [False, True])
 def test_rankgrid_downsample_from_grid_equals_from_coords(xmajor):
     """rd_rankgrid_downsample_grid (marks the SparseConv2d(k3, s2, p1) output set from the input rank GRID, no host-side row count)
