@@ -48,6 +48,16 @@ def main():
         print(f"step {(t1 - t0) / 1e6:7.2f} ms: GPU busy (union) {busy / 1e6:6.2f} ms, idle {(t1 - t0 - busy) / 1e6:5.2f} ms "
               f"({len(gaps)} gaps, {big / 1e6:.2f} ms in gaps > 20 us), kernel-sum {ksum / 1e6:6.2f} ms, {len(seg)} kernels; per queue "
               + ", ".join(f"{q}: {v / 1e6:.1f}" for q, v in sorted(per_q.items(), key=lambda kv: -kv[1])[:5]))
+        if os.environ.get("RD_TRACE_TOP"):
+            import collections
+            for q in sorted(per_q, key=per_q.get, reverse=True)[:3]:
+                agg = collections.defaultdict(lambda: [0, 0])
+                for s_, e_, n_, q_ in seg:
+                    if q_ == q:
+                        a_ = agg[n_.split("(")[0][:60]]
+                        a_[0] += 1
+                        a_[1] += e_ - s_
+                print(f"     queue {q}:", [(k, c, round(t / 1e6, 2)) for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]])
         worst = sorted(gaps, reverse=True)[:6]
         print("     largest gaps (us, next kernel):", [(round(g / 1e3, 1), n[:40]) for g, n in worst])
 
