@@ -278,9 +278,14 @@ int rd_opt_chunk_elems(void);   /* elements per chunk of the chunk table */
 int rd_pack_grads(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, float *flat, void *stream);
 int rd_grad_norm(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, float max_norm, float *out2, float *ws,
                  int64_t ws_bytes, const float *flat_grad, float grad_scale, void *stream);
-/* step = 1-based update count (bias correction).  clip_dev may be NULL (no clipping) or out2 of rd_grad_norm. */
-int rd_adam_step(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, float lr, float beta1, float beta2, float eps,
-                 float weight_decay, int step, const float *clip_dev, const float *flat_grad, float grad_scale, void *stream);
+/* step = 1-based count of optimizer steps (bias correction).  clip_dev may be NULL (no clipping) or out2 of rd_grad_norm.
+ * A tensor whose `grad` is NULL sits the step out as in torch.optim.Adam (only the decoupled decay p *= 1 - wd*lr of
+ * OptimWrapper.step touches it; rd_grad_norm ignores it, rd_pack_grads packs zeros); skipped_dev (NULL = all zero) holds per tensor
+ * how many steps it sat out so far, so that its own bias-correction count is step - skipped[t].  Hyper-parameters are doubles: the
+ * reference forms 1 - wd*lr, lr / (1 - beta1^t), sqrt(1 - beta2^t) in Python floats before they meet fp32 tensors. */
+int rd_adam_step(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, double lr, double beta1, double beta2, double eps,
+                 double weight_decay, int step, const int32_t *skipped_dev, const float *clip_dev, const float *flat_grad, float grad_scale,
+                 void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * J. Depthwise KxK convolution on channels-last maps (ConvNeXt dwconv 7x7, groups = C, padding K/2).  Replaces cuDNN's

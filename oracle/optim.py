@@ -33,19 +33,31 @@ def one_cycle(step, total_step, lr_max=1e-3, moms=(0.95, 0.85), div_factor=10.0,
 
 
 def clip_grad_norm(grads, max_norm=10.0):
-    """torch.nn.utils.clip_grad_norm_: total 2-norm over all grads; scale by max_norm/(norm+1e-6) clamped to 1."""
-    total = torch.sqrt(sum((g.detach().double() ** 2).sum() for g in grads)).float()
+    """torch.nn.utils.clip_grad_norm_ (train_utils.py:62): total 2-norm over the gradients that exist (None entries are skipped);
+    every gradient is scaled by max_norm/(norm+1e-6) clamped to 1."""
+    present = [g for g in grads if g is not None]
+    total = torch.sqrt(sum((g.detach().double() ** 2).sum() for g in present)).float() if present else torch.zeros(())
     coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
-    return total, [g * coef for g in grads]
+    return total, [None if g is None else g * coef for g in grads]
 
 
-def adam_true_wd_step(params, grads, exp_avg, exp_avg_sq, step, lr, beta1, beta2=0.99, wd=0.01, eps=1e-8):
-    """One OptimWrapper.step(): decoupled decay then torch.optim.Adam (no amsgrad, wd=0).  In place.
-    `step` is the 1-based count after this update."""
-    bc1 = 1 - beta1 ** step
-    bc2 = 1 - beta2 ** step
-    for p, g, m, v in zip(params, grads, exp_avg, exp_avg_sq):
+def adam_true_wd_step(params, grads, exp_avg, exp_avg_sq, steps, lr, beta1, beta2=0.99, wd=0.01, eps=1e-8):
+    """One OptimWrapper.step() (fastai_optim.py:135-152): decoupled decay `p *= 1 - wd*lr` on EVERY trainable parameter, then
+    torch.optim.Adam (no amsgrad, weight_decay 0), which skips a parameter whose gradient is None -- no moment update and no step
+    count for it.  In place.  `steps[i]` is parameter i's own count of Adam updates so far (an int `steps` = the same count for
+    all, incremented here into nothing: the caller passes the 1-based count AFTER this update, as before)."""
+    per_param = not isinstance(steps, int)
+    for i, (p, g, m, v) in enumerate(zip(params, grads, exp_avg, exp_avg_sq)):
         p.mul_(1 - wd * lr)
+        if g is None:
+            continue
+        if per_param:
+            steps[i] += 1
+            step = steps[i]
+        else:
+            step = steps
+        bc1 = 1 - beta1 ** step
+        bc2 = 1 - beta2 ** step
         m.mul_(beta1).add_(g, alpha=1 - beta1)
         v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
         denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)

@@ -17,7 +17,7 @@ void set_error(const char *fmt, ...) {
 using namespace rd;
 
 extern "C" const char *rd_last_error(void) { return rd::g_err; }
-extern "C" int rd_abi_version(void) { return 1; }
+extern "C" int rd_abi_version(void) { return 2; }
 extern "C" int rd_device_ok(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void k_gradnorm_partial(const rd_opt_tensor *_
     const int2 ch = chunks[blockIdx.x];
     const rd_opt_tensor t = tensors[ch.x];
     const float *g = grad_ptr(tensors, t, flat) + ch.y;
-    const int64_t n = min((int64_t)OPT_CHUNK, t.numel - ch.y);
+    const int64_t n = t.grad ? min((int64_t)OPT_CHUNK, t.numel - ch.y) : 0;       // no gradient this step: torch's clip skips the tensor
     float s = 0.f;
     for (int64_t i = threadIdx.x; i < n; i += 256) {
         float v = g[i] * grad_scale;
@@ -58,24 +58,44 @@ __global__ void k_gradnorm_final(const float *partial, int n, float max_norm, fl
     }
 }
 
-__global__ __launch_bounds__(256) void k_adam(const rd_opt_tensor *__restrict__ tensors, const int2 *__restrict__ chunks, float lr, float beta1,
-                                              float beta2, float eps, float wd, float bc1, float bc2_sqrt, const float *__restrict__ clip,
+// A tensor whose gradient pointer is NULL is only decayed (OptimWrapper.step decays every trainable parameter, torch.optim.Adam
+// skips parameters without a gradient: no moment update, no step count).  `skipped[t]` = how many optimizer steps tensor t sat out,
+// so its own Adam step count is step - skipped[t]; with skipped == NULL every tensor is at `step` and the bias corrections come
+// precomputed (in double) from the host.
+__global__ __launch_bounds__(256) void k_adam(const rd_opt_tensor *__restrict__ tensors, const int2 *__restrict__ chunks, double lr, float beta1,
+                                              float beta2, float eps, float decay, float step_size0, float bc2_sqrt0, double beta1d, double beta2d,
+                                              int step, const int32_t *__restrict__ skipped, const float *__restrict__ clip,
                                               const float *__restrict__ flat, float grad_scale) {
+    __shared__ float sh[2];
     const int2 ch = chunks[blockIdx.x];
     const rd_opt_tensor t = tensors[ch.x];
     const int64_t n = min((int64_t)OPT_CHUNK, t.numel - ch.y);
     float *p = t.param + ch.y;
+    if (t.grad == nullptr) {
+        for (int64_t i = threadIdx.x; i < n; i += 256) p[i] *= decay;
+        return;
+    }
+    float step_size = step_size0, bc2_sqrt = bc2_sqrt0;
+    if (skipped != nullptr) {
+        if (threadIdx.x == 0) {
+            const int own = step - skipped[ch.x];
+            sh[0] = (float)(lr / (1.0 - pow(beta1d, (double)own)));
+            sh[1] = (float)sqrt(1.0 - pow(beta2d, (double)own));
+        }
+        __syncthreads();
+        step_size = sh[0];
+        bc2_sqrt = sh[1];
+    }
     const float *g = grad_ptr(tensors, t, flat) + ch.y;
     float *m = t.exp_avg + ch.y, *v = t.exp_avg_sq + ch.y;
     const float cc = (clip ? clip[1] : 1.f) * grad_scale;
-    const float decay = 1.f - wd * lr, step = lr / bc1;
     for (int64_t i = threadIdx.x; i < n; i += 256) {
         const float gi = g[i] * cc;
         float pi = p[i] * decay;
         const float mi = beta1 * m[i] + (1.f - beta1) * gi;
         const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        pi -= step * (mi / denom);
+        pi -= step_size * (mi / denom);
         p[i] = pi;
         m[i] = mi;
         v[i] = vi;
@@ -87,8 +107,12 @@ __global__ __launch_bounds__(256) void k_pack_grads(const rd_opt_tensor *__restr
     const int2 ch = chunks[blockIdx.x];
     const rd_opt_tensor t = tensors[ch.x];
     const int64_t n = min((int64_t)OPT_CHUNK, t.numel - ch.y);
-    const float *g = t.grad + ch.y;
     float *d = flat + (t.exp_avg - tensors[0].exp_avg) + ch.y;
+    if (t.grad == nullptr) {                    // no gradient on this rank: contributes zeros to the sum
+        for (int64_t i = threadIdx.x; i < n; i += 256) d[i] = 0.f;
+        return;
+    }
+    const float *g = t.grad + ch.y;
     for (int64_t i = threadIdx.x; i < n; i += 256) d[i] = g[i];
 }
 
@@ -109,14 +133,16 @@ extern "C" int rd_grad_norm(const rd_opt_tensor *tensors_dev, const int32_t *chu
     return check_launch("rd_grad_norm");
 }
 
-extern "C" int rd_adam_step(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, float lr, float beta1, float beta2,
-                            float eps, float weight_decay, int step, const float *clip_dev, const float *flat_grad, float grad_scale,
-                            void *stream) {
+extern "C" int rd_adam_step(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, double lr, double beta1, double beta2,
+                            double eps, double weight_decay, int step, const int32_t *skipped_dev, const float *clip_dev,
+                            const float *flat_grad, float grad_scale, void *stream) {
     RD_REQUIRE(step >= 1, "rd_adam_step: step must be >= 1");
     if (n_chunks <= 0) return RD_OK;
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    k_adam<<<n_chunks, 256, 0, S(stream)>>>(tensors_dev, reinterpret_cast<const int2 *>(chunks_dev), lr, beta1, beta2, eps, weight_decay,
-                                            (float)bc1, (float)sqrt(bc2), clip_dev, flat_grad, grad_scale);
+    // scalars are formed in double like the reference's Python floats and rounded once (torch applies them to fp32 tensors)
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+    k_adam<<<n_chunks, 256, 0, S(stream)>>>(tensors_dev, reinterpret_cast<const int2 *>(chunks_dev), lr, (float)beta1, (float)beta2, (float)eps,
+                                            (float)(1.0 - weight_decay * lr), (float)(lr / bc1), (float)sqrt(bc2), beta1, beta2, step, skipped_dev,
+                                            clip_dev, flat_grad, grad_scale);
     return check_launch("rd_adam_step");
 }
 

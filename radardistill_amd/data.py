@@ -20,8 +20,21 @@ class SyntheticDistillDataset:
 
     @classmethod
     def from_cfg(cls, cfg):
+        """Geometry from a loaded reference yaml.  VOXEL_SIZE lives in the DATA_PROCESSOR list (the last entry that carries one
+        wins, as each processor overwrites `self.voxel_size`: data_processor.py:116-124,142-146,263-268;
+        radar_distill_train.yaml:62-63); feature counts are the lengths of the POINT_FEATURE_ENCODING lists
+        (point_feature_encoder.py:86-90)."""
         d = cfg.DATA_CONFIG
-        return cls(cfg.CLASS_NAMES, d.POINT_CLOUD_RANGE, d.VOXEL_SIZE, d.get('NUM_POINT_FEATURES', 5), d.get('RADAR_NUM_POINT_FEATURES', 6))
+        voxel = d.get('VOXEL_SIZE', None)
+        for proc in d.get('DATA_PROCESSOR', None) or []:
+            if proc.get('VOXEL_SIZE', None) is not None:
+                voxel = proc['VOXEL_SIZE']
+        if voxel is None:
+            raise KeyError("no VOXEL_SIZE in DATA_CONFIG.DATA_PROCESSOR (transform_points_to_voxels[_placeholder]) nor DATA_CONFIG")
+        enc = d.get('POINT_FEATURE_ENCODING', None) or {}
+        n_pts = len(enc['used_feature_list']) if 'used_feature_list' in enc else d.get('NUM_POINT_FEATURES', 5)
+        n_rad = len(enc['radar_used_feature_list']) if 'radar_used_feature_list' in enc else d.get('RADAR_NUM_POINT_FEATURES', 6)
+        return cls(cfg.CLASS_NAMES, d.POINT_CLOUD_RANGE, list(voxel), n_pts, n_rad)
 
 
 def collate_batch(batch_list, _unused=False):

@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(CSRC, "librdamd.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "rdamd.h")
 
-c_int, c_i64, c_f32, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+c_int, c_i64, c_f32, c_f64, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 
 
 class ConvIndex(ctypes.Structure):
@@ -97,7 +97,7 @@ SIGNATURES = {
     "rd_opt_chunk_elems": (c_int, []),
     "rd_pack_grads": (c_int, [_P, _P, c_int, _P, _P]),
     "rd_grad_norm": (c_int, [_P, _P, c_int, c_f32, _P, _P, c_i64, _P, c_f32, _P]),
-    "rd_adam_step": (c_int, [_P, _P, c_int, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, _P, _P, c_f32, _P]),
+    "rd_adam_step": (c_int, [_P, _P, c_int, c_f64, c_f64, c_f64, c_f64, c_f64, c_int, _P, _P, _P, c_f32, _P]),
     "rd_dwconv_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "rd_dwconv_wgrad_ws_bytes": (c_i64, [c_int, c_int, c_int, c_int, c_int]),
     "rd_dwconv_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_i64, _P]),

@@ -1,4 +1,4 @@
-from .dynamic_pillar_vfe import DynamicPillarVFESimple2D, Radar_DynamicPillarVFESimple2D
+from .dynamic_pillar_vfe import DynamicPillarVFESimple2D, Radar_DynamicPillarVFESimple2D, Radar_DynamicPillarVFESimple2D_Test
 from .pillar_vfe import PillarVFE
 from .vfe_template import VFETemplate
 
@@ -7,5 +7,6 @@ __all__ = {
     'VFETemplate': VFETemplate,
     'DynamicPillarVFESimple2D': DynamicPillarVFESimple2D,
     'Radar_DynamicPillarVFESimple2D': Radar_DynamicPillarVFESimple2D,
+    'Radar_DynamicPillarVFESimple2D_Test': Radar_DynamicPillarVFESimple2D_Test,      # radar_distill_val.yaml:67
     'PillarVFE': PillarVFE,                 # padded-voxel input format
 }

@@ -148,3 +148,10 @@ class Radar_DynamicPillarVFESimple2D(DynamicPillarVFESimple2D):
     """Reads `radar_points`, writes `radar_pillar_features` / `radar_pillar_coords` (dynamic_pillar_vfe.py:255-313)."""
     POINTS_KEY = "radar_points"
     OUT_PREFIX = "radar_"
+
+
+class Radar_DynamicPillarVFESimple2D_Test(DynamicPillarVFESimple2D):
+    """The eval-graph radar VFE of radar_distill_val.yaml:67 (dynamic_pillar_vfe.py:315-375): the radar-only test dataset hands its
+    sweep over as `points`, the outputs go to the student's `radar_pillar_*` keys; state_dict names are the base class's."""
+    POINTS_KEY = "points"
+    OUT_PREFIX = "radar_"

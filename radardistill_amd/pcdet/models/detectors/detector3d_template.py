@@ -232,6 +232,14 @@ class Detector3DTemplate(nn.Module):
         epoch = checkpoint.get('epoch', -1)
         it = checkpoint.get('it', 0.0)
         self._load_state_dict(checkpoint['model_state'], strict=True)
-        if optimizer is not None and checkpoint.get('optimizer_state', None) is not None:
-            optimizer.load_state_dict(checkpoint['optimizer_state'])
+        if optimizer is not None:
+            if checkpoint.get('optimizer_state', None) is not None:
+                optimizer.load_state_dict(checkpoint['optimizer_state'])
+            else:
+                # the moments may sit next to the checkpoint as `<name>_optim.<ext>` (detector3d_template.py:484-490)
+                assert filename[-4] == '.', filename
+                optimizer_filename = '%s_optim.%s' % (filename[:-4], filename[-3:])
+                if os.path.exists(optimizer_filename):
+                    optimizer_ckpt = torch.load(optimizer_filename, map_location=loc_type, weights_only=True)
+                    optimizer.load_state_dict(optimizer_ckpt['optimizer_state'])
         return it, epoch

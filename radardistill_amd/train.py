@@ -53,7 +53,9 @@ class _OptTensor(ctypes.Structure):
 class FusedAdamOneCycle:
     """`adam_onecycle` optimizer of the reference (OptimWrapper over Adam with true_wd, bn_wd) as fused HIP launches."""
 
-    def __init__(self, params, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, wd=0.01, grad_clip=10.0):
+    def __init__(self, params, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, wd=0.01, grad_clip=10.0, ref_groups=None):
+        """ref_groups: the reference optimizer's numbering of these parameters -- a list of lists of indices into the trainable
+        `params` (build_optimizer derives the two groups of split_bn_bias); only state_dict()/load_state_dict() use it."""
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -87,7 +89,13 @@ class FusedAdamOneCycle:
         self._slot_sig = [None] * self._ring
         self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)
         self.ws = torch.empty(self.n_chunks, dtype=torch.float32, device=dev)
-        self._zero = {}
+        self.ref_groups = [list(g) for g in ref_groups] if ref_groups is not None else [list(range(len(self.params))), []]
+        if sorted(i for g in self.ref_groups for i in g) != list(range(len(self.params))):
+            raise ValueError("ref_groups must number every trainable parameter exactly once")
+        # torch.optim.Adam keeps a step count PER PARAMETER and skips parameters whose gradient is None; `skipped[i]` = optimizer
+        # steps parameter i sat out (device copy refreshed only when it changes: never, in the distillation model)
+        self.skipped = np.zeros(len(self.params), dtype=np.int32)
+        self.skipped_dev = None
         self._static_cols = None
         self.flat_grad = None          # data parallelism: see enable_flat_allreduce()
         self.process_group = None
@@ -112,11 +120,10 @@ class FusedAdamOneCycle:
         grads = []
         for i, p in enumerate(self.params):
             g = p.grad
-            if g is None:                      # parameter unused this step: zero gradient (Adam still decays its moments)
-                g = self._zero.get(i)
-                if g is None:
-                    g = self._zero[i] = torch.zeros_like(p)
-            elif not g.is_contiguous() or g.dtype != torch.float32:
+            if g is None:                      # parameter unused this step: NULL = only the decoupled decay touches it (Adam skips it)
+                grads.append(0)
+                continue
+            if not g.is_contiguous() or g.dtype != torch.float32:
                 g = p.grad = g.float().contiguous()
             grads.append(g.data_ptr())
         sig = (tuple(grads), tuple(p.data_ptr() for p in self.params))
@@ -174,24 +181,96 @@ class FusedAdamOneCycle:
             clip = self.norm_out
         self.step_count += 1
         check(L.rd_adam_step(_p(table), _p(self.chunks_dev), self.n_chunks, float(self.lr), float(self.mom), float(self.beta2),
-                             float(self.eps), float(self.wd), self.step_count, _p(clip), _p(flat), scale, _stream()), "rd_adam_step")
+                             float(self.eps), float(self.wd), self.step_count, _p(self.skipped_dev), _p(clip), _p(flat), scale, _stream()),
+              "rd_adam_step")
+        absent = [i for i, p in enumerate(self.params) if p.grad is None]
+        if absent:                             # they sat this step out: their own Adam step count stays behind from now on
+            self.skipped[absent] += 1
+            self.skipped_dev = torch.from_numpy(self.skipped.copy()).to(self.params[0].device)
         A.bump_weights_epoch()                 # parameters changed through raw pointers: invalidate cached weight layouts
         return self.norm_out
 
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr, "mom": self.mom}
+        """The inner torch.optim.Adam's state_dict as the reference stores it under `optimizer_state` (OptimWrapper passes
+        state_dict through to `self.opt`, fastai_optim.py:162-164; written by train_utils.py:253-270): per-parameter
+        {step, exp_avg, exp_avg_sq} keyed by the reference's parameter numbering (group 0: non-BatchNorm leaves, group 1: BatchNorm
+        leaves, split_bn_bias fastai_optim.py:16-28), parameters that never had a gradient carry no state."""
+        state, off = {}, self.offsets
+        order = [i for g in self.ref_groups for i in g]
+        for idx, i in enumerate(order):
+            own = self.step_count - int(self.skipped[i])
+            if own <= 0:
+                continue
+            p = self.params[i]
+            state[idx] = {"step": own, "exp_avg": self.exp_avg[off[i]:off[i + 1]].view(p.shape).clone(),
+                          "exp_avg_sq": self.exp_avg_sq[off[i]:off[i + 1]].view(p.shape).clone()}
+        groups, base = [], 0
+        for g in self.ref_groups:
+            groups.append({"lr": self.lr, "betas": (self.mom, self.beta2), "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                           "params": list(range(base, base + len(g)))})
+            base += len(g)
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
+        """Accepts the layout above -- i.e. a reference checkpoint's `optimizer_state` -- and the flat dictionary this class wrote
+        in round 1 ({step, exp_avg, exp_avg_sq, lr, mom})."""
+        if "state" in sd and "param_groups" in sd:
+            sizes = [len(g["params"]) for g in sd["param_groups"]]
+            if sizes != [len(g) for g in self.ref_groups]:
+                raise RuntimeError(f"optimizer state has parameter groups of sizes {sizes}, this model has "
+                                   f"{[len(g) for g in self.ref_groups]} (non-BatchNorm / BatchNorm trainable parameters)")
+            order = [i for g in self.ref_groups for i in g]
+            steps = np.zeros(len(self.params), dtype=np.int64)
+            self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+            for idx, st in sd["state"].items():
+                i = order[int(idx)]
+                p = self.params[i]
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise RuntimeError(f"optimizer state {idx}: moment shape {tuple(st['exp_avg'].shape)} != parameter shape {tuple(p.shape)}")
+                steps[i] = int(st["step"])
+                self.exp_avg[self.offsets[i]:self.offsets[i + 1]].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[self.offsets[i]:self.offsets[i + 1]].copy_(st["exp_avg_sq"].reshape(-1))
+            self.step_count = int(steps.max()) if len(steps) else 0
+            self.skipped = (self.step_count - steps).astype(np.int32)
+            self.skipped_dev = torch.from_numpy(self.skipped.copy()).to(self.params[0].device) if self.skipped.any() else None
+            g0 = sd["param_groups"][0]
+            self.lr, self.mom = float(g0["lr"]), float(g0["betas"][0])
+            return
+        if not {"step", "exp_avg", "exp_avg_sq"} <= set(sd):
+            raise RuntimeError("unrecognised optimizer state: expected torch.optim.Adam's {state, param_groups} or this build's flat "
+                               "{step, exp_avg, exp_avg_sq, lr, mom}")
         self.step_count = int(sd["step"])
         self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.lr, self.mom = sd["lr"], sd["mom"]
+        self.skipped[:] = 0
+        self.skipped_dev = None
+
+
+def reference_param_groups(model):
+    """The reference optimizer's parameter numbering (optimization/__init__.py:19-33 + fastai_optim.py:16-28,93-96,117-123): the
+    model is flattened to its leaf modules in definition order, BatchNorm leaves are split off into a second group, and each group
+    lists its trainable parameters.  Returns (trainable parameters in model.parameters() order, [group0 indices, group1 indices])."""
+    bn_types = (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d, torch.nn.BatchNorm3d, torch.nn.SyncBatchNorm)
+    params = [p for p in model.parameters() if p.requires_grad]
+    index = {id(p): i for i, p in enumerate(params)}
+    groups, seen = ([], []), set()
+    for leaf in (m for m in model.modules() if not any(True for _ in m.children())):
+        dst = groups[1] if isinstance(leaf, bn_types) else groups[0]
+        for p in leaf.parameters():
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                dst.append(index[id(p)])
+    missing = [i for i in range(len(params)) if i not in set(groups[0]) | set(groups[1])]
+    groups[0].extend(missing)           # parameters owned by non-leaf modules (none in this model): the reference never optimises them
+    return params, [groups[0], groups[1]]
 
 
 def build_optimizer(model, optim_cfg):
     if optim_cfg.OPTIMIZER != 'adam_onecycle':
         raise NotImplementedError("the distill config trains with adam_onecycle")
     betas = tuple(optim_cfg.get('BETAS', (0.9, 0.99)))
-    return FusedAdamOneCycle(model.parameters(), lr=3e-3, betas=betas, wd=optim_cfg.WEIGHT_DECAY, grad_clip=optim_cfg.GRAD_NORM_CLIP)
+    params, groups = reference_param_groups(model)
+    return FusedAdamOneCycle(params, lr=3e-3, betas=betas, wd=optim_cfg.WEIGHT_DECAY, grad_clip=optim_cfg.GRAD_NORM_CLIP, ref_groups=groups)
 
 
 def build_scheduler(optimizer, total_iters_each_epoch, total_epochs, last_epoch, optim_cfg):
@@ -216,8 +295,10 @@ def model_state_to_cpu(model_state):
 
 
 def checkpoint_state(model=None, optimizer=None, epoch=None, it=None):
-    """Same dictionary layout as the reference (`epoch`, `it`, `model_state`, `optimizer_state`, `version`), so checkpoints written
-    here load with the reference's load_params_from_file / load_params_with_optimizer and vice versa (state_dict names are equal)."""
+    """Same dictionary layout as the reference (`epoch`, `it`, `model_state`, `optimizer_state`, `version`; train_utils.py:253-270):
+    `model_state` names equal the reference's and `optimizer_state` is torch.optim.Adam's own {state, param_groups} in the
+    reference's parameter numbering (FusedAdamOneCycle.state_dict), which FusedAdamOneCycle.load_state_dict also reads back from a
+    reference checkpoint."""
     optim_state = optimizer.state_dict() if optimizer is not None else None
     model_state = None
     if model is not None:

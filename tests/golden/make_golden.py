@@ -275,9 +275,66 @@ def g7_pillar():
     save("g7_pillar.npz", **out)
 
 
+def g8_optim():
+    """A13: the reference's own build_optimizer / OptimWrapper / OneCycle + clip_grad_norm_ loop (tools/train_utils/optimization/
+    __init__.py:19-54, fastai_optim.py:104-235, learning_schedules_fastai.py:44-77, train_utils.py:44-64) on the small problem
+    of tests/golden/optim_case.py.  The package is pure torch and imports as shipped."""
+    import importlib.util
+    from torch.nn.utils import clip_grad_norm_
+    from tests.golden import optim_case as OC
+    pkg_dir = os.path.join(L.REF_ROOT, "tools/train_utils/optimization")
+    spec = importlib.util.spec_from_file_location("ref_optimization", os.path.join(pkg_dir, "__init__.py"), submodule_search_locations=[pkg_dir])
+    ref = importlib.util.module_from_spec(spec)
+    sys.modules["ref_optimization"] = ref
+    spec.loader.exec_module(ref)
+    torch.manual_seed(0)
+    model = OC.OptimCaseNet()
+    sd = model.state_dict(); seeded_fill_(sd, seed=18); model.load_state_dict(sd)
+    cfg = L.AttrDict(OC.OPTIM_CFG)
+    opt = ref.build_optimizer(model, cfg)
+    sched, _ = ref.build_scheduler(opt, total_iters_each_epoch=OC.TOTAL_ITERS_EACH_EPOCH, total_epochs=OC.TOTAL_EPOCHS, last_epoch=-1, optim_cfg=cfg)
+    names = [n for n, _ in OC.trainable(model)]
+    out = {"names": np.array(names), "lr0": np.float64(opt.lr), "mom0": np.float64(opt.mom)}
+    lrs, moms, norms, snaps = [], [], [], []
+    for it in range(OC.N_STEPS):
+        sched.step(it)
+        lrs.append(float(opt.lr)); moms.append(float(opt.mom))
+        model.train()
+        opt.zero_grad()
+        OC.assign_grads(model, it)
+        norms.append(float(clip_grad_norm_(model.parameters(), cfg.GRAD_NORM_CLIP)))
+        opt.step()
+        snaps.append(torch.cat([p.detach().reshape(-1) for _, p in OC.trainable(model)]).clone())
+    out["lr"], out["mom"], out["total_norm"] = np.array(lrs), np.array(moms), np.array(norms, dtype=np.float32)
+    out["params_after"] = torch.stack(snaps)
+    # inner torch.optim.Adam state in the reference's own parameter numbering (two groups: non-BatchNorm leaves, BatchNorm leaves)
+    osd = opt.state_dict()
+    by_id = {id(p): n for n, p in model.named_parameters()}
+    order = [by_id[id(p)] for g in opt.opt.param_groups for p in g["params"]]
+    out["ref_param_order"] = np.array(order)
+    out["ref_group_sizes"] = np.array([len(g["params"]) for g in osd["param_groups"]])
+    for idx, name in enumerate(order):
+        st = osd["state"].get(idx)
+        out[f"has_state_{name}"] = np.array(st is not None)
+        if st is not None:
+            out[f"step_{name}"] = np.array(int(st["step"]))
+            out[f"exp_avg_{name}"] = st["exp_avg"]; out[f"exp_avg_sq_{name}"] = st["exp_avg_sq"]
+    save("g8_optim.npz", **out)
+
+
+def _fresh_reference_modules():
+    """Every set starts from a clean slate: leaf files of the reference (and the placeholders / bridges an earlier set installed for
+    them, e.g. g4's reduced iou3d_nms_utils) are dropped from sys.modules so the next set imports what IT needs."""
+    for k in [k for k in sys.modules if k == "pcdet" or k.startswith("pcdet.") or k == "ref_optimization" or k.startswith("ref_optimization.")]:
+        del sys.modules[k]
+
+
 if __name__ == "__main__":
     torch.set_grad_enabled(False)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
-    fns = {"g1": g1_vfe, "g2": g2_dense_enc, "g3": g3_radar_distill, "g4": g4_center_head, "g5": g5_conv5, "g6": g6_decode, "g7": g7_pillar}
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    fns = {"g1": g1_vfe, "g2": g2_dense_enc, "g3": g3_radar_distill, "g4": g4_center_head, "g5": g5_conv5, "g6": g6_decode, "g7": g7_pillar,
+           "g8": g8_optim}
     for w in which:
+        _fresh_reference_modules()
+        torch.set_grad_enabled(False)
         fns[w]()

@@ -16,7 +16,7 @@ def test_library_exports_every_header_symbol():
     for s in syms:
         assert hasattr(L, s), s
     assert set(syms) == set(native.SIGNATURES)
-    assert L.rd_abi_version() == 1
+    assert L.rd_abi_version() == 2
     assert L.rd_rankgrid_bytes(32 * 1024) == (2 * 1024 + 1 + 1) * 4
 
 
@@ -62,6 +62,39 @@ def test_reference_yaml_loads_unchanged(monkeypatch):
     assert c.DATA_CONFIG.POINT_FEATURE_ENCODING.radar_used_feature_list == ['x', 'y', 'z', 'rcs', 'vx', 'vy']
     cfg_from_list(["OPTIMIZATION.LR", "0.002", "DATA_CONFIG.DATA_AUGMENTOR.DISABLE_AUG_LIST", "gt_sampling_distill,foo"], c)
     assert c.OPTIMIZATION.LR == 0.002 and c.DATA_CONFIG.DATA_AUGMENTOR.DISABLE_AUG_LIST == ["gt_sampling_distill", "foo"]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/tools/cfgs"), reason="reference tree only exists in the build container")
+@pytest.mark.parametrize("yaml_name,modules,total,trainable", [
+    ("radar_distill_train.yaml", ["DynamicPillarVFESimple2D", "Radar_DynamicPillarVFESimple2D", "PillarRes18BackBone8x", "Radar_PillarRes18BackBone8x",
+                                  "BaseBEVBackboneV2", "Radar_Distill", "CenterHead", "Radar_CenterHead"], 41075593, 24910077),
+    ("radar_distill_val.yaml", ["Radar_DynamicPillarVFESimple2D_Test", "Radar_PillarRes18BackBone8x", "Radar_Distill", "Radar_CenterHead"],
+     24910845, 24910077)])
+def test_build_network_on_the_unmodified_reference_yamls(monkeypatch, yaml_name, modules, total, trainable):
+    """tools/train.py:143 / tools/test.py: cfg_from_yaml_file + build_network on the reference's own files, dataset facts taken from
+    the yaml as the reference's dataset does (VOXEL_SIZE from DATA_PROCESSOR, feature counts from POINT_FEATURE_ENCODING).
+    Parameter counts are the reference modules' (SURVEY 8(a): 512 + 544 + 2 x 6 479 872 + 7 936 512 + 16 682 577 + 2 x 1 747 852;
+    768 frozen DCN biases among the student's)."""
+    from radardistill_amd.data import SyntheticDistillDataset
+    from radardistill_amd.pcdet.config import AttrDict, cfg_from_yaml_file
+    from radardistill_amd.pcdet.models import build_network
+    monkeypatch.chdir("/root/reference/tools")
+    c = cfg_from_yaml_file("cfgs/radar_distill/" + yaml_name, AttrDict())
+    ds = SyntheticDistillDataset.from_cfg(c)
+    assert list(ds.grid_size) == [1440, 1440, 40] and list(ds.voxel_size) == [0.075, 0.075, 0.2]
+    m = build_network(model_cfg=c.MODEL, num_class=len(c.CLASS_NAMES), dataset=ds)
+    assert [type(x).__name__ for x in m.module_list] == modules
+    assert sum(p.numel() for p in m.parameters()) == total
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == trainable
+    if "train" in yaml_name:
+        # the student-init checkpoint of ckpt.py loads: every teacher tensor lands twice, except the radar VFE's 15-column Linear
+        from radardistill_amd.ckpt import student_init_state
+        teacher = {k: torch.full_like(v, 0.5) for k, v in m.state_dict().items() if not k.startswith("radar_") and k != "global_step"}
+        init = student_init_state({"epoch": 1, "it": 2, "optimizer_state": None, "version": "x", "model_state": teacher})
+        _, updated = m._load_state_dict(init["model_state"], strict=False)
+        skipped = [k for k in init["model_state"] if k not in updated]
+        assert skipped == ["radar_vfe.pfn_layers.0.linear.weight"]
+        assert float(m.radar_backbone_3d.conv2[0][0].weight.mean()) == 0.5 and float(m.backbone_2d.blocks[0][1].weight.mean()) == 0.5
 
 
 def test_batched_head_loss_equals_per_head_loss_and_oracle(monkeypatch):

@@ -827,3 +827,85 @@ def test_dense_enc_at_1024_bev_size_modes_agree_and_linear():
     finally:
         K.set_conv_math("f32")
     close(res["bf16x3"][0], res["f32"][0], rtol=1e-3, atol=1e-4); close(res["bf16x3"][1], res["f32"][1], rtol=1e-3, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------ the reference yaml's own geometry
+def _build_real_geometry():
+    """radar_distill_train.yaml:6,63: +-54 m at 0.075 m pillars -> 1440 x 1440 grid, 180 x 180 head map (the yaml itself does not
+    travel to the GPU box: same MODEL block from tools/cfgs/radar_distill/bench_512.yaml, geometry overridden)."""
+    import os
+    from radardistill_amd.data import SyntheticDistillDataset
+    from radardistill_amd.pcdet.config import AttrDict, cfg_from_yaml_file
+    from radardistill_amd.pcdet.models import build_network
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    c = cfg_from_yaml_file(os.path.join(root, "tools/cfgs/radar_distill/bench_512.yaml"), AttrDict())
+    pc_range = [-54.0, -54.0, -5.0, 54.0, 54.0, 3.0]
+    c.DATA_CONFIG.POINT_CLOUD_RANGE = pc_range
+    c.DATA_CONFIG.VOXEL_SIZE = [0.075, 0.075, 0.2]
+    c.MODEL.RADAR_BACKBONE_2D.POINT_CLOUD_RANGE = pc_range
+    c.MODEL.RADAR_BACKBONE_2D.VOXEL_SIZE = [0.075, 0.075, 8.0]
+    c.MODEL.RADAR_BACKBONE_2D.GRID_SIZE = [1440, 1440, 1]
+    ds = SyntheticDistillDataset.from_cfg(c)
+    assert list(ds.grid_size) == [1440, 1440, 40]
+    torch.manual_seed(0)
+    m = build_network(model_cfg=c.MODEL, num_class=len(c.CLASS_NAMES), dataset=ds)
+    sd = m.state_dict(); seeded_fill_(sd, seed=78); m.load_state_dict(sd)
+    return m.to(DEV), pc_range, [0.075, 0.075, 0.2], ds.grid_size
+
+
+def test_training_step_at_the_reference_yaml_geometry():
+    """One distillation step at 1440 x 1440 / 0.075 m (B = 2), checked through size-independent properties: pillar coordinates
+    bit-exact vs the oracle voxeliser (division by 0.075, int(-54.0) origin), the two arithmetic modes agree on every loss term,
+    swapping the two samples leaves the (batch-mean) loss unchanged, every trainable parameter receives a finite gradient."""
+    from oracle import vfe as ovfe
+    from radardistill_amd import kernels as K
+    from radardistill_amd.pcdet.models import model_fn_decorator
+    model, pc_range, voxel, gs = _build_real_geometry()
+    B = 2
+    batch = make_batch(batch_size=B, n_lidar=35000, n_radar=2000, n_boxes=30, grid=540, seed=21)      # +-54 m
+    fn = model_fn_decorator()
+
+    def run(bd):
+        model.zero_grad(set_to_none=True)
+        model.train()
+        loss, tb, _ = fn(model, {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in bd.items()})
+        loss.backward()
+        return float(loss), {k: float(v) for k, v in tb.items()}, {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.requires_grad}
+
+    state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    loss_a, tb_a, grads = run(batch)
+    assert np.isfinite(loss_a)
+    for k, g in grads.items():
+        assert g is not None and bool(torch.isfinite(g).all()), k
+    # (1) pillar coordinates of both branches at this geometry, bit-exact (eval pass keeps them in the dict)
+    model.eval()
+    bd = {k: (torch.from_numpy(v).to(DEV) if isinstance(v, np.ndarray) else v) for k, v in batch.items()}
+    with torch.no_grad():
+        for mod, key, pre in ((model.vfe, "points", ""), (model.radar_vfe, "radar_points", "radar_")):
+            out = mod({key: bd[key], "batch_size": B})
+            _, _, unq, _, _ = ovfe.voxelize(torch.from_numpy(batch[key]), pc_range, voxel, (1440, 1440))
+            unq = unq.long()                   # key = b * 1440^2 + cx * 1440 + cy, sorted: the reference's pillar order (:243-248)
+            ref = torch.stack((unq // (1440 * 1440), unq % 1440, (unq % (1440 * 1440)) // 1440), dim=1).int()       # (b, y, x)
+            got = out[pre + "pillar_coords"].cpu()
+            assert got.shape == ref.shape and torch.equal(got, ref), key
+    # (2) bf16x3 arithmetic on the same weights and batch
+    model.load_state_dict(state0)
+    K.set_conv_math("bf16x3")
+    try:
+        loss_b, tb_b, _ = run(batch)
+    finally:
+        K.set_conv_math("f32")
+    assert abs(loss_a - loss_b) <= 1e-3 * abs(loss_a), (loss_a, loss_b)
+    for k in tb_a:
+        assert abs(tb_a[k] - tb_b[k]) <= 2e-3 * abs(tb_a[k]) + 1e-5, (k, tb_a[k], tb_b[k])
+    # (3) sample permutation
+    model.load_state_dict(state0)
+    perm = {"batch_size": B, "gt_boxes": batch["gt_boxes"][::-1].copy()}
+    for key in ("points", "radar_points"):
+        p = batch[key]
+        parts = [p[p[:, 0] == b].copy() for b in range(B)][::-1]
+        for b, part in enumerate(parts):
+            part[:, 0] = b
+        perm[key] = np.concatenate(parts, 0)
+    loss_c, tb_c, _ = run(perm)
+    assert abs(loss_a - loss_c) <= 2e-4 * abs(loss_a), (loss_a, loss_c)
