@@ -1,160 +1,132 @@
-"""CenterNet target helpers with the reference's arithmetic (pcdet/models/model_utils/centernet_utils.py:9-69,462-497)."""
+"""CenterNet geometry helpers behind the CenterHead (module path and public names of the reference's
+pcdet/models/model_utils/centernet_utils.py; written from the semantics, arithmetic order kept where parity needs it).
+
+Training targets are produced on the device by targets.hip (`rd_center_targets`); the host functions here serve the CPU / waymo
+fallback of `assign_targets` and are what the GPU kernel is checked against (fixture g4 pins them: heat-maps bit-exact).
+The eval-time decode works on rows x channels (channels-last) maps, the layout every dense kernel of this build produces.
+"""
 import numpy as np
 import torch
 
 
+# ------------------------------------------------------------------------------------------ gaussian targets (host)
 def gaussian_radius(height, width, min_overlap=0.5):
-    a1 = 1
-    b1 = (height + width)
-    c1 = width * height * (1 - min_overlap) / (1 + min_overlap)
-    sq1 = (b1 ** 2 - 4 * a1 * c1).sqrt()
-    r1 = (b1 + sq1) / 2
-    a2 = 4
-    b2 = 2 * (height + width)
-    c2 = (1 - min_overlap) * width * height
-    sq2 = (b2 ** 2 - 4 * a2 * c2).sqrt()
-    r2 = (b2 + sq2) / 2
-    a3 = 4 * min_overlap
-    b3 = -2 * min_overlap * (height + width)
-    c3 = (min_overlap - 1) * width * height
-    sq3 = (b3 ** 2 - 4 * a3 * c3).sqrt()
-    r3 = (b3 + sq3) / 2
-    return torch.min(torch.min(r1, r2), r3)
+    """Largest centre displacement r that keeps a (height x width) box at IoU >= min_overlap with itself, minimum over the three
+    ways two such boxes can overlap (CornerNet).  Each case is the larger root of a r^2 - b r + c = 0; the fp32 operation order
+    of every coefficient follows centernet_utils.py:9-35 so that int(radius) -- and with it every heat-map cell -- is bit-equal.
+    height / width: fp32 tensors (box extent in cells)."""
+    o = min_overlap
+    span = height + width
+    quadratics = (
+        # (b, 4 a c)                                                                 a        c
+        (span, 4 * (width * height * (1 - o) / (1 + o))),                          # 1        area (1-o)/(1+o)
+        (2 * span, 16 * ((1 - o) * width * height)),                               # 4        (1-o) area
+        (-2 * o * span, 4 * (4 * o) * ((o - 1) * width * height)),                 # 4 o      (o-1) area
+    )
+    roots = [(b + (b ** 2 - four_ac).sqrt()) / 2 for b, four_ac in quadratics]
+    return torch.stack(roots, dim=0).amin(dim=0)
 
 
-_GAUSS_CACHE = {}
-
-
-def gaussian2D(shape, sigma=1):
-    m, n = [(ss - 1.) / 2. for ss in shape]
-    y, x = np.ogrid[-m:m + 1, -n:n + 1]
-    h = np.exp(-(x * x + y * y) / (2 * sigma * sigma))
-    h[h < np.finfo(h.dtype).eps * h.max()] = 0
-    return h
+_PATCHES = {}
 
 
 def gaussian_patch(radius):
-    """float32 (2r+1, 2r+1) patch, sigma = (2r+1)/6, computed in float64 like the reference then cast."""
-    g = _GAUSS_CACHE.get(radius)
-    if g is None:
-        d = 2 * radius + 1
-        g = torch.from_numpy(gaussian2D((d, d), sigma=d / 6)).float()
-        _GAUSS_CACHE[radius] = g
-    return g
+    """fp32 (2r+1) x (2r+1) bump exp(-d^2 / 2 sigma^2) with sigma = (2r+1)/6, evaluated in float64 and cut below
+    eps * peak before the cast (centernet_utils.py:38-44 as called from :50-51).  Cached per radius."""
+    patch = _PATCHES.get(radius)
+    if patch is None:
+        side = 2 * radius + 1
+        sigma = side / 6
+        axis = np.arange(-radius, radius + 1, dtype=np.float64)
+        bump = np.exp(-(axis[None, :] * axis[None, :] + axis[:, None] * axis[:, None]) / (2 * sigma * sigma))
+        bump[bump < np.finfo(bump.dtype).eps * bump.max()] = 0
+        patch = _PATCHES[radius] = torch.from_numpy(bump).float()
+    return patch
 
 
 def draw_gaussian_to_heatmap(heatmap, center, radius, k=1, valid_mask=None):
-    gaussian = gaussian_patch(int(radius))
-    x, y = int(center[0]), int(center[1])
-    height, width = heatmap.shape[0:2]
-    left, right = min(x, radius), min(width - x, radius + 1)
-    top, bottom = min(y, radius), min(height - y, radius + 1)
-    masked_heatmap = heatmap[y - top:y + bottom, x - left:x + right]
-    masked_gaussian = gaussian[radius - top:radius + bottom, radius - left:radius + right].to(heatmap.device)
-    if min(masked_gaussian.shape) > 0 and min(masked_heatmap.shape) > 0:
-        if valid_mask is not None:
-            masked_gaussian = masked_gaussian * valid_mask[y - top:y + bottom, x - left:x + right].float()
-        torch.max(masked_heatmap, masked_gaussian * k, out=masked_heatmap)
+    """heatmap (H, W) <- max(heatmap, k * bump centred on the integer cell `center` = (x, y)), clipped at the map border."""
+    H, W = heatmap.shape[0:2]
+    cx, cy, r = int(center[0]), int(center[1]), int(radius)
+    x0, x1 = max(cx - r, 0), min(cx + r + 1, W)
+    y0, y1 = max(cy - r, 0), min(cy + r + 1, H)
+    if x1 <= x0 or y1 <= y0:
+        return heatmap
+    bump = gaussian_patch(r)[y0 - (cy - r):y1 - (cy - r), x0 - (cx - r):x1 - (cx - r)].to(heatmap.device)
+    if valid_mask is not None:
+        bump = bump * valid_mask[y0:y1, x0:x1].float()
+    window = heatmap[y0:y1, x0:x1]
+    torch.maximum(window, bump * k, out=window)
     return heatmap
 
 
+# ------------------------------------------------------------------------------------------ axis-aligned DIoU (IouRegLoss, torch path)
 def bbox3d_overlaps_diou(pred_boxes, gt_boxes):
-    """Axis-aligned 3-D DIoU (centernet_utils.py:462-497)."""
-    assert pred_boxes.shape[0] == gt_boxes.shape[0]
-    qmin, qmax = pred_boxes[:, :2] - 0.5 * pred_boxes[:, 3:5], pred_boxes[:, :2] + 0.5 * pred_boxes[:, 3:5]
-    gmin, gmax = gt_boxes[:, :2] - 0.5 * gt_boxes[:, 3:5], gt_boxes[:, :2] + 0.5 * gt_boxes[:, 3:5]
-    inter_max_xy, inter_min_xy = torch.minimum(qmax, gmax), torch.maximum(qmin, gmin)
-    out_max_xy, out_min_xy = torch.maximum(qmax, gmax), torch.minimum(qmin, gmin)
-    volume_pred = pred_boxes[:, 3] * pred_boxes[:, 4] * pred_boxes[:, 5]
-    volume_gt = gt_boxes[:, 3] * gt_boxes[:, 4] * gt_boxes[:, 5]
-    inter_h = torch.minimum(pred_boxes[:, 2] + 0.5 * pred_boxes[:, 5], gt_boxes[:, 2] + 0.5 * gt_boxes[:, 5]) - \
-        torch.maximum(pred_boxes[:, 2] - 0.5 * pred_boxes[:, 5], gt_boxes[:, 2] - 0.5 * gt_boxes[:, 5])
-    inter_h = torch.clamp(inter_h, min=0)
-    inter = torch.clamp(inter_max_xy - inter_min_xy, min=0)
-    volume_inter = inter[:, 0] * inter[:, 1] * inter_h
-    volume_union = volume_gt + volume_pred - volume_inter
-    inter_diag = torch.pow(gt_boxes[:, 0:3] - pred_boxes[:, 0:3], 2).sum(-1)
-    outer_h = torch.maximum(gt_boxes[:, 2] + 0.5 * gt_boxes[:, 5], pred_boxes[:, 2] + 0.5 * pred_boxes[:, 5]) - \
-        torch.minimum(gt_boxes[:, 2] - 0.5 * gt_boxes[:, 5], pred_boxes[:, 2] - 0.5 * pred_boxes[:, 5])
-    outer_h = torch.clamp(outer_h, min=0)
-    outer = torch.clamp(out_max_xy - out_min_xy, min=0)
-    outer_diag = outer[:, 0] ** 2 + outer[:, 1] ** 2 + outer_h ** 2
-    return torch.clamp(volume_inter / volume_union - inter_diag / outer_diag, min=-1.0, max=1.0)
+    """Distance-IoU of axis-aligned 3-D boxes (x, y, z, dx, dy, dz, ...): IoU - |c_p - c_g|^2 / diag(enclosing box)^2, in [-1, 1]
+    (centernet_utils.py:462-497; the fused loss kernel centerloss.hip computes the same expression per object slot)."""
+    if pred_boxes.shape[0] != gt_boxes.shape[0]:
+        raise ValueError("bbox3d_overlaps_diou: the two box lists must pair up")
+    p_lo, p_hi = pred_boxes[:, 0:3] - 0.5 * pred_boxes[:, 3:6], pred_boxes[:, 0:3] + 0.5 * pred_boxes[:, 3:6]
+    g_lo, g_hi = gt_boxes[:, 0:3] - 0.5 * gt_boxes[:, 3:6], gt_boxes[:, 0:3] + 0.5 * gt_boxes[:, 3:6]
+    common = torch.clamp(torch.minimum(p_hi, g_hi) - torch.maximum(p_lo, g_lo), min=0)
+    hull = torch.clamp(torch.maximum(p_hi, g_hi) - torch.minimum(p_lo, g_lo), min=0)
+    vol_common = common[:, 0] * common[:, 1] * common[:, 2]
+    vol_pred = pred_boxes[:, 3] * pred_boxes[:, 4] * pred_boxes[:, 5]
+    vol_gt = gt_boxes[:, 3] * gt_boxes[:, 4] * gt_boxes[:, 5]
+    centre_dist2 = torch.pow(gt_boxes[:, 0:3] - pred_boxes[:, 0:3], 2).sum(-1)
+    hull_diag2 = hull[:, 0] ** 2 + hull[:, 1] ** 2 + hull[:, 2] ** 2
+    return torch.clamp(vol_common / (vol_gt + vol_pred - vol_common) - centre_dist2 / hull_diag2, min=-1.0, max=1.0)
 
 
 # ------------------------------------------------------------------------------------------ inference decode
-def _gather_feat(feat, ind, mask=None):
-    dim = feat.size(2)
-    ind = ind.unsqueeze(2).expand(ind.size(0), ind.size(1), dim)
-    feat = feat.gather(1, ind)
-    if mask is not None:
-        mask = mask.unsqueeze(2).expand_as(feat)
-        feat = feat[mask].view(-1, dim)
-    return feat
+def _rows(x):
+    """(B, C, H, W) -> (B, H*W, C); free for the channels-last maps the dense kernels write."""
+    return x.permute(0, 2, 3, 1).reshape(x.shape[0], -1, x.shape[1])
 
 
-def _transpose_and_gather_feat(feat, ind):
-    feat = feat.permute(0, 2, 3, 1).contiguous()
-    feat = feat.view(feat.size(0), -1, feat.size(3))
-    return _gather_feat(feat, ind)
+def _peaks(scores, K):
+    """The K highest entries of each sample's (C, H, W) score volume, descending: (score, cell = y*W + x, class, y, x).
+    (The reference takes K per class and then K of those, centernet_utils.py:155-171 -- the same set, since every global top-K
+    entry is inside its own class's top K.)"""
+    B, C, H, W = scores.shape
+    top, flat = torch.topk(_rows(scores).reshape(B, -1), K)              # index = cell * C + class
+    cell = torch.div(flat, C, rounding_mode='floor')
+    return top, cell, (flat - cell * C).int(), torch.div(cell, W, rounding_mode='floor').float(), (cell % W).float()
 
 
-def _topk(scores, K=40):
-    """Top-K peaks over classes and cells (centernet_utils.py:155-171)."""
-    batch, num_class, height, width = scores.size()
-    topk_scores, topk_inds = torch.topk(scores.flatten(2, 3), K)
-    topk_inds = topk_inds % (height * width)
-    topk_ys = (topk_inds // width).float()
-    topk_xs = (topk_inds % width).int().float()
-    topk_score, topk_ind = torch.topk(topk_scores.view(batch, -1), K)
-    topk_classes = (topk_ind // K).int()
-    topk_inds = _gather_feat(topk_inds.view(batch, -1, 1), topk_ind).view(batch, K)
-    topk_ys = _gather_feat(topk_ys.view(batch, -1, 1), topk_ind).view(batch, K)
-    topk_xs = _gather_feat(topk_xs.view(batch, -1, 1), topk_ind).view(batch, K)
-    return topk_score, topk_inds, topk_classes, topk_ys, topk_xs
+def _at(feature_map, cell):
+    """Rows of a (B, C, H, W) map at `cell` (B, K) -> (B, K, C)."""
+    rows = _rows(feature_map)
+    return torch.take_along_dim(rows, cell.unsqueeze(-1).expand(-1, -1, rows.shape[-1]), dim=1)
 
 
 def decode_bbox_from_heatmap(heatmap, rot_cos, rot_sin, center, center_z, dim, iou=None, rectifier=0.,
                              point_cloud_range=None, voxel_size=None, feature_map_stride=None, vel=None, K=100,
                              circle_nms=False, score_thresh=None, post_center_limit_range=None):
-    """centernet_utils.py:231-308 (the IoU-rectified variant this fork uses).  Dense maps may be channels-last views; only K
-    cells per sample are gathered from them."""
-    batch_size, num_class, _, _ = heatmap.size()
+    """Boxes of the K strongest heat-map peaks per sample: centre = (peak cell + predicted sub-cell offset) * stride * voxel + range
+    origin, z / size taken as predicted (`dim` already exponentiated by the caller), yaw = atan2(sin, cos), optional velocity;
+    kept when the centre lies inside `post_center_limit_range` and the score exceeds `score_thresh`; with an IoU head the score
+    becomes score^(1-rectifier) * clamp(iou, 0, 1)^rectifier (centernet_utils.py:231-308, the IoU-rectified variant of this fork).
+    Returns one {'pred_boxes', 'pred_scores', 'pred_labels'} per sample (labels local to the head)."""
     if circle_nms:
         raise NotImplementedError("circle_nms is 'not checked yet' in the reference (centernet_utils.py:236-239)")
-    scores, inds, class_ids, ys, xs = _topk(heatmap, K=K)
-    center = _transpose_and_gather_feat(center, inds).view(batch_size, K, 2)
-    rot_sin = _transpose_and_gather_feat(rot_sin, inds).view(batch_size, K, 1)
-    rot_cos = _transpose_and_gather_feat(rot_cos, inds).view(batch_size, K, 1)
-    center_z = _transpose_and_gather_feat(center_z, inds).view(batch_size, K, 1)
-    dim = _transpose_and_gather_feat(dim, inds).view(batch_size, K, 3)
-    if iou is not None:
-        iou = _transpose_and_gather_feat(iou, inds).view(batch_size, K, 1)
-    angle = torch.atan2(rot_sin, rot_cos)
-    xs = xs.view(batch_size, K, 1) + center[:, :, 0:1]
-    ys = ys.view(batch_size, K, 1) + center[:, :, 1:2]
-    xs = xs * feature_map_stride * voxel_size[0] + point_cloud_range[0]
-    ys = ys * feature_map_stride * voxel_size[1] + point_cloud_range[1]
-    box_part_list = [xs, ys, center_z, dim, angle]
+    if post_center_limit_range is None:
+        raise ValueError("decode_bbox_from_heatmap needs post_center_limit_range")
+    K = min(int(K), heatmap.shape[1] * heatmap.shape[2] * heatmap.shape[3])
+    scores, cell, labels, ys, xs = _peaks(heatmap, K)
+    offset = _at(center, cell)
+    origin = offset.new_tensor([float(point_cloud_range[0]), float(point_cloud_range[1])])
+    pitch = offset.new_tensor([float(voxel_size[0]), float(voxel_size[1])])
+    xy = (torch.stack((xs, ys), dim=-1) + offset) * feature_map_stride * pitch + origin
+    parts = [xy, _at(center_z, cell), _at(dim, cell), torch.atan2(_at(rot_sin, cell), _at(rot_cos, cell))]
     if vel is not None:
-        vel = _transpose_and_gather_feat(vel, inds).view(batch_size, K, 2)
-        box_part_list.append(vel)
-    final_box_preds = torch.cat(box_part_list, dim=-1)
-    final_scores = scores.view(batch_size, K)
-    final_class_ids = class_ids.view(batch_size, K)
-    assert post_center_limit_range is not None
-    mask = (final_box_preds[..., :3] >= post_center_limit_range[:3]).all(2)
-    mask &= (final_box_preds[..., :3] <= post_center_limit_range[3:]).all(2)
+        parts.append(_at(vel, cell))
+    boxes = torch.cat(parts, dim=-1)
+    keep = ((boxes[..., :3] >= post_center_limit_range[:3]) & (boxes[..., :3] <= post_center_limit_range[3:])).all(-1)
     if score_thresh is not None:
-        mask &= (final_scores > score_thresh)
-    ret_pred_dicts = []
-    for k in range(batch_size):
-        cur_mask = mask[k]
-        cur_boxes = final_box_preds[k, cur_mask]
-        cur_scores = final_scores[k, cur_mask]
-        cur_labels = final_class_ids[k, cur_mask]
-        if iou is not None:
-            iou_preds = torch.clamp(iou[k, cur_mask].view(-1), min=0, max=1.)
-            cur_scores = torch.pow(cur_scores, 1 - rectifier) * torch.pow(iou_preds, rectifier)
-        ret_pred_dicts.append({'pred_boxes': cur_boxes, 'pred_scores': cur_scores, 'pred_labels': cur_labels})
-    return ret_pred_dicts
+        keep &= scores > score_thresh
+    if iou is not None:
+        quality = torch.clamp(_at(iou, cell).squeeze(-1), min=0, max=1.)
+        scores = torch.pow(scores, 1 - rectifier) * torch.pow(quality, rectifier)
+    return [{'pred_boxes': boxes[b, keep[b]], 'pred_scores': scores[b, keep[b]], 'pred_labels': labels[b, keep[b]]}
+            for b in range(boxes.shape[0])]
