@@ -40,10 +40,10 @@ def parse():
                     help="arithmetic of the implicit-GEMM conv kernels: bf16x3 = fp32 operands split into bf16 hi+lo, three bf16 MFMAs per "
                          "product, fp32 accumulate (~4e-6 relative error, inside the 1e-3 parity bound; parity-tested in "
                          "tests/test_gpu_model.py::test_bf16x3_conv_math_parity); f32 = exact fp32 MFMA")
-    ap.add_argument("--other-math-steps", type=int, default=5, help="extra steps timed in the other arithmetic mode after the timed region "
-                    "(reported as 'other_math'; 0 = skip)")
+    ap.add_argument("--other-math-steps", type=int, default=-1, help="steps timed in the other arithmetic mode after the timed region "
+                    "(reported as 'other_math'; -1 = the same count as --steps, 0 = skip)")
     ap.add_argument("--cpu-baseline-grid", type=int, default=512)
-    ap.add_argument("--cpu-baseline-batch", type=int, default=4)
+    ap.add_argument("--cpu-baseline-batch", type=int, default=1)
     return ap.parse_args()
 
 
@@ -84,31 +84,76 @@ def device_batch(batch, device):
     return out
 
 
-def cpu_baseline(grid, B=4):
-    """The CPU oracle (a port: the reference itself cannot run here) timed on this host: one full training
-    forward + backward on a bounded sample (B samples) of the bench geometry.  Reported, never the target."""
+def _median_time(fn, warm=3, reps=10, budget_s=40.0):
+    """SURVEY 8(d) / BASELINE.md section 3 protocol: `warm` untimed calls, then the median of `reps` timed ones.  `budget_s` bounds
+    the whole measurement (the default bench run must end within minutes): when it runs out the repetitions stop early, never below
+    3 timed calls; what was actually run is reported."""
+    t_start = time.perf_counter()
+    for _ in range(warm):
+        fn()
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > budget_s and len(times) >= 3:
+            break
+    return float(np.median(times)), len(times)
+
+
+def cpu_baseline(grid, B=1):
+    """The CPU oracle (kind "port": the reference itself cannot run here -- spconv / torch_scatter / DCN are absent) timed
+    on this host's cores: (1) the C4-shaped training step at B samples -- teacher forward, student forward + backward, clip +
+    decoupled-decay Adam -- and (2) BASELINE configs[0] (C1): radar-only PillarNet forward, 1000 radar points, 128 x 128 BEV.
+    Warm-up 3 + median of 10 each.  Reported, never the target."""
+    from oracle import optim as ooptim
     from oracle import pillarnet as opn
-    model, cfg, (pc_range, voxel, gs) = build(os.path.join(ROOT, "tools/cfgs/radar_distill/bench_512.yaml"), grid, "cpu")
     from radardistill_amd.synthetic import make_batch
+    cores = min(len(os.sched_getaffinity(0)), 16)      # the GPU box gives a 16-core share; cpu_count() reports the whole host
+    torch.set_num_threads(cores)
+    model, cfg, (pc_range, voxel, gs) = build(os.path.join(ROOT, "tools/cfgs/radar_distill/bench_512.yaml"), grid, "cpu")
     state = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    for k, p in model.named_parameters():
-        if p.requires_grad:
-            state[k].requires_grad_(True)
+    names = [k for k, p in model.named_parameters() if p.requires_grad]
+    for k in names:
+        state[k].requires_grad_(True)
+    params = [state[k] for k in names]
+    m1 = [torch.zeros_like(p) for p in params]; m2 = [torch.zeros_like(p) for p in params]
     b = make_batch(batch_size=B, n_lidar=35000, n_radar=2000, n_boxes=30, grid=grid, seed=0)
     ob = {"points": torch.from_numpy(b["points"]), "radar_points": torch.from_numpy(b["radar_points"]),
           "gt_boxes": torch.from_numpy(b["gt_boxes"]), "batch_size": B}
-    cores = min(len(os.sched_getaffinity(0)), 16)      # the GPU box gives a 16-core share; cpu_count() reports the host
-    torch.set_num_threads(cores)
-    t0 = time.time()
-    loss, _, _ = opn.forward_train(state, ob, pc_range, voxel, gs)
-    loss.mean().backward()
-    dt = time.time() - t0
-    return {"value": round(B / dt, 4), "unit": "samples/sec", "cores": cores, "kind": "port",
-            "sample": f"1 training step (teacher fwd + student fwd/bwd, no optimizer) at B={B}, {grid}x{grid} BEV, 35k+2k points: {dt:.1f} s"}
+    it = [0]
+
+    def train_step():
+        it[0] += 1
+        for p in params:
+            p.grad = None
+        loss, _, _ = opn.forward_train(state, ob, pc_range, voxel, gs, run_teacher_head=True)
+        loss.mean().backward()
+        _, clipped = ooptim.clip_grad_norm([p.grad for p in params], 10.0)
+        lr, mom = ooptim.one_cycle(it[0], 1000)
+        with torch.no_grad():
+            ooptim.adam_true_wd_step([p.data for p in params], clipped, m1, m2, it[0], lr, mom)
+
+    dt, n = _median_time(train_step)
+    out = {"value": round(B / dt, 4), "unit": "samples/sec", "cores": cores, "kind": "port",
+           "sample": f"C4 shape at B={B}: full training step (teacher fwd incl. head, student fwd/bwd, clip + Adam) at {grid}x{grid} BEV, 35k LiDAR + 2k "
+                     f"radar points, 30 boxes; 3 warm-up + median of {n} steps = {dt:.2f} s per step"}
+    # C1: radar-only PillarNet forward (eval), G = 128, 1000 radar points, B = 1
+    model1, _, (pcr1, vox1, gs1) = build(os.path.join(ROOT, "tools/cfgs/radar_distill/bench_512.yaml"), 128, "cpu")
+    st1 = {k: v.detach() for k, v in model1.state_dict().items()}
+    b1 = make_batch(batch_size=1, n_lidar=16, n_radar=1000, n_boxes=1, grid=128, seed=0)
+    rp = torch.from_numpy(b1["radar_points"])
+    with torch.no_grad():
+        dt1, n1 = _median_time(lambda: opn.forward_radar_only(st1, rp, 1, pcr1, vox1, gs1), budget_s=15.0)
+    out["c1_radar_only_forward"] = {"value": round(1.0 / dt1, 3), "unit": "samples/sec", "ms": round(dt1 * 1e3, 2),
+                                    "sample": f"BASELINE configs[0]: radar-only PillarNet forward, 1000 radar points, 128x128 BEV, B=1; 3 warm-up + median of {n1}"}
+    return out
 
 
 def main():
     args = parse()
+    if args.other_math_steps < 0:
+        args.other_math_steps = args.steps
     from radardistill_amd import dist as D
     world, rank, local_rank = D.env_world()
     if not torch.cuda.is_available():
@@ -172,7 +217,7 @@ def main():
     K.BN_PROFILE = []
     if os.environ.get("RD_BENCH_NO_HOOKS"):          # diagnostic: cost of the per-launch HIP events themselves
         K.CONV_PROFILE = K.BN_PROFILE = None
-    K.WGRAD_PROFILE = [] if os.environ.get("RD_BENCH_SHAPES") else None
+    K.WGRAD_PROFILE = [] if K.CONV_PROFILE is not None else None
     barrier()
     t0 = time.perf_counter()
     for it in range(args.warmup, args.warmup + args.steps):
@@ -193,10 +238,12 @@ def main():
         A.WGRAD_STREAM[0] = False
         K.CONV_PROFILE = []
         K.BN_PROFILE = []
+        K.WGRAD_PROFILE = []
         for it in range(args.warmup + args.steps, args.warmup + args.steps + 2):
             step(it)
         torch.cuda.synchronize()
-        iso_prof, K.CONV_PROFILE = K.CONV_PROFILE, None
+        iso_prof, K.CONV_PROFILE = K.CONV_PROFILE + K.WGRAD_PROFILE, None
+        K.WGRAD_PROFILE = None
         iso_bn, K.BN_PROFILE = K.BN_PROFILE, None
         os.environ["RD_TEACHER_STREAM"] = prev_env
         A.WGRAD_STREAM[0] = prev_w
@@ -227,6 +274,9 @@ def main():
         print(f"[bench] host enqueue time per step (ms, no device sync): forward+loss {ht[:, 0].mean():.1f}  backward {ht[:, 1].mean():.1f}  "
               f"optimizer {ht[:, 2].mean():.1f}", file=sys.stderr, flush=True)
         samples = args.batch * world * args.steps
+        # every MFMA convolution launch of the timed region: forward, data gradient (CONV_PROFILE) and weight gradient (WGRAD_PROFILE),
+        # each tagged with the instantiation the C dispatch picks (kernels._kernel_tag / conv_wgrad)
+        prof = list(prof) + list(wprof or [])
         all_ms = [a.elapsed_time(b) for a, b, _, _, _ in prof]
         all_flops = [(f if pairs is None else float(pairs.item()) * f) for _, _, pairs, f, _ in prof]
         if os.environ.get("RD_BENCH_SHAPES"):
@@ -234,27 +284,19 @@ def main():
             for ms, fl, (_, _, _, _, shape) in zip(all_ms, all_flops, prof):
                 a = agg.setdefault(shape, [0, 0.0, 0.0]); a[0] += 1; a[1] += ms; a[2] += fl
             for shape, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                print(f"[shape in_rows,Cin,Cout,taps,mode,tile={shape}] launches/step {n / prof_steps:.1f} ms/step {ms / prof_steps:.3f} "
+                print(f"[shape in_rows,Cin,Cout,taps,mode,kernel={shape}] launches/step {n / prof_steps:.1f} ms/step {ms / prof_steps:.3f} "
                       f"TF/s {fl / (ms * 1e-3) / 1e12:.1f}", file=sys.stderr)
-            wagg = {}
-            for e0, e1, pairs, f, shape in (wprof or []):
-                a = wagg.setdefault(shape, [0, 0.0, 0.0]); a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += (f if pairs is None else float(pairs.item()) * f)
-            for shape, (n, ms, fl) in sorted(wagg.items(), key=lambda kv: -kv[1][1]):
-                print(f"[wgrad in_rows,Cin,Cout,taps,mode={shape}] launches/step {n / prof_steps:.1f} ms/step {ms / prof_steps:.3f} "
-                      f"TF/s {fl / (ms * 1e-3) / 1e12:.1f}", file=sys.stderr)
-        # roofline of the dominant kernel = the forward / data-gradient convolution instantiation with the largest summed time in the
-        # timed region (kernels._kernel_tag mirrors the C dispatch): the halo-staged dense 3x3 kernel or the gathered implicit GEMM
+        # roofline of the DOMINANT kernel = the MFMA instantiation with the largest summed time in the timed region, weight gradients
+        # included.  achieved = ALGORITHMIC flops (dense 2 k^2 Cin Cout rows, sparse 2 pairs Cin Cout) / launch duration.
         b3 = args.math == "bf16x3"
-        by_kern, fl_kern = {}, {}
+        by_kern, fl_kern, n_kern = {}, {}, {}
         for i, p in enumerate(prof):
-            if p[4][4] < 10:                                                       # mode >= 10: exact-fp32 transposed-weight data gradient
-                by_kern[p[4][5]] = by_kern.get(p[4][5], 0.0) + all_ms[i]
-                fl_kern[p[4][5]] = fl_kern.get(p[4][5], 0.0) + all_flops[i]
-        # three instantiations sit within a few percent of each other in summed time (~5 ms per step each), so the plain maximum flips
-        # from run to run: among those within 10 % of the largest time, name the one that does the most work
-        top = max(by_kern.values()) if by_kern else 0.0
-        dom = max((k for k in by_kern if by_kern[k] >= 0.9 * top), key=lambda k: fl_kern[k]) if by_kern else 128
-        sel = [i for i, p in enumerate(prof) if p[4][5] == dom and p[4][4] < 10]
+            tag = p[4][5]
+            by_kern[tag] = by_kern.get(tag, 0.0) + all_ms[i]
+            fl_kern[tag] = fl_kern.get(tag, 0.0) + all_flops[i]
+            n_kern[tag] = n_kern.get(tag, 0) + 1
+        dom = max(by_kern, key=lambda k: by_kern[k]) if by_kern else 128
+        sel = [i for i, p in enumerate(prof) if p[4][5] == dom]
         kernel_ms = [all_ms[i] for i in sel]
         flops = [all_flops[i] for i in sel]
         n_launch = len(sel)
@@ -262,57 +304,64 @@ def main():
         achieved = (sum(flops) / max(n_launch, 1)) / (avg_ms * 1e-3) / 1e12 if n_launch else 0.0
         iso = None
         if iso_prof:
-            isel = [p for p in iso_prof if p[4][5] == dom and p[4][4] < 10]
+            isel = [p for p in iso_prof if p[4][5] == dom]
             if isel:
                 ims = sum(a.elapsed_time(b) for a, b, _, _, _ in isel) / len(isel)
                 ifl = sum((f if pairs is None else float(pairs.item()) * f) for _, _, pairs, f, _ in isel) / len(isel)
                 iso = (ims, ifl / (ims * 1e-3) / 1e12)
+        arith = ("fp32 operands split to bf16 hi+lo, 3 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate" if b3 else
+                 "exact fp32 on v_mfma_f32_32x32x2_f32")
         names = {
-            "d3_128": ("k_conv_d3_b3<8,16,128> (dense stride-1 3x3 conv, forward and data gradient: 8x16-pixel halo staged and split to bf16 hi+lo once "
-                       "per 32-channel chunk, 9 taps by LDS offset, pre-split weights, 3 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate)",
-                       "k_conv_d3_b3<8, 16, 128, true>"),
-            "d3_64": ("k_conv_d3_b3<8,8,64> (dense stride-1 3x3 conv on the halo-staged bf16x3 kernel, 8x8-pixel x 64-channel tiles)", "k_conv_d3_b3<8, 8, 64, true>"),
-            128: (("k_conv_igemm_b3<128,128,false> (gathered implicit-GEMM conv: sparse / 1x1 / strided / transposed; fp32 activations split to bf16 hi+lo in LDS, "
-                   "3 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate)", "k_conv_igemm_b3<128, 128, false, false>") if b3 else
-                  ("k_conv_igemm<128,128,2,2,false> (gathered implicit-GEMM conv: sparse + dense 3x3 / 1x1 / transposed, exact fp32 MFMA)", "k_conv_igemm<128, 128, 2, 2, false")),
-            64: (("k_conv_igemm_b3<64,64,false> (gathered implicit-GEMM conv, 64x64 tiles, bf16x3)", "k_conv_igemm_b3<64, 64, false, false>") if b3 else
-                 ("k_conv_igemm<64,64,2,2,false> (gathered implicit-GEMM conv, 64x64 tiles, exact fp32 MFMA)", "k_conv_igemm<64, 64, 2, 2, false")),
+            "d3_128": ("k_conv_d3_b3<8,16,128> (dense stride-1 3x3 conv, forward and data gradient: halo-staged 8x16-pixel tile)", "k_conv_d3_b3<8, 16, 128"),
+            "d3_64": ("k_conv_d3_b3<8,8,64> (dense stride-1 3x3 conv, halo-staged 8x8-pixel x 64-channel tile)", "k_conv_d3_b3<8, 8, 64"),
+            128: ("k_conv_igemm%s<128,128> (gathered implicit-GEMM conv: sparse / 1x1 / strided / transposed, forward and data gradient)" % ("_b3" if b3 else ""),
+                  "k_conv_igemm_b3<128, 128" if b3 else "k_conv_igemm<128, 128"),
+            64: ("k_conv_igemm%s<64,64> (gathered implicit-GEMM conv, 64x64 tiles)" % ("_b3" if b3 else ""), "k_conv_igemm_b3<64, 64" if b3 else "k_conv_igemm<64, 64"),
+            "wgrad_b3_128": ("k_conv_wgrad_b3<false,128> (weight gradient GEMM: M = Cout tile 128, N = Cin tile 128 of one tap, K = rows; row chunks "
+                             "combined with fp32 atomics)", "k_conv_wgrad_b3<false, 128"),
+            "wgrad_b3_64": ("k_conv_wgrad_b3<false,64> (weight gradient GEMM, Cin tile 64)", "k_conv_wgrad_b3<false, 64"),
+            "wgrad_b3_deform_128": ("k_conv_wgrad_b3<true,128> (DCNv2 weight gradient: input rows blended from 4 bilinear corners while staged)", "k_conv_wgrad_b3<true, 128"),
+            "wgrad_f32_128": ("k_conv_wgrad<false,128> (weight gradient GEMM, exact fp32 MFMA)", "k_conv_wgrad<false, 128"),
+            "wgrad_f32_64": ("k_conv_wgrad<false,64> (weight gradient GEMM, exact fp32 MFMA, Cin tile 64)", "k_conv_wgrad<false, 64"),
+            "wgrad_f32_deform_128": ("k_conv_wgrad<true,128> (DCNv2 weight gradient, exact fp32 MFMA)", "k_conv_wgrad<true, 128"),
+            "wgrad_f32_deform_64": ("k_conv_wgrad<true,64> (DCNv2 weight gradient, exact fp32 MFMA)", "k_conv_wgrad<true, 64"),
         }
-        kname, pmc_key = names[dom]
+        kname, pmc_key = names.get(dom, (str(dom), str(dom)))
         peak = PEAK_BF16_MFMA_TFLOPS if b3 else PEAK_F32_MFMA_TFLOPS
-        if b3:
-            # every algorithmic multiply-add is three bf16 MFMA products (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi): price the kernel
-            # against the dense bf16 MFMA peak with the flops it really issues
-            algorithmic, achieved = achieved, 3.0 * achieved
-        else:
-            algorithmic = achieved
-        traffic = None          # HBM bytes per launch from the committed PMC passes (cannot be collected live inside bench.py)
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", f"round1_pmc_hbm_traffic_{args.math}.json")))["kernels"]
-            traffic = next(v["hbm_bytes_per_launch_corrected"] for k, v in pm.items() if pmc_key in k)
-        except Exception:
-            pass
+        issue = 3.0 if b3 else 1.0        # bf16x3: every algorithmic multiply-add is three bf16 MFMA products
+        traffic = None          # HBM bytes per launch from the committed PMC passes of this command (cannot be collected live inside bench.py)
+        for rnd in ("round2", "round1"):
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm_traffic_{args.math}.json")))["kernels"]
+                traffic = next(v["hbm_bytes_per_launch_corrected"] for k, v in pm.items() if pmc_key in k)
+                break
+            except Exception:
+                pass
+        step_ms = dt / args.steps * 1e3
         out = {
             "metric": "samples/sec", "value": round(samples / dt, 3), "unit": "samples/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": round(step_ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16x3 (fp32 storage and accumulate)" if b3 else "f32", "data": "synthetic",
             "config": {"workload": "RadarDistill full training step (BASELINE configs[3]): frozen LiDAR teacher fwd + radar student "
                                    "fwd/bwd (VFE, SparseEnc, CMA+DCNv2, DenseEnc, CenterHead, AFD+PFD+detection losses) + clip + Adam",
                        "bev": f"{args.grid}x{args.grid}", "pillar_m": 0.2, "lidar_pts": 35000, "radar_pts": 2000, "boxes": 30,
                        "conv_math": args.math, "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}" + ("" if world == 1 else ("/ddp" if os.environ.get("RD_DDP", "flat") == "torch" else "/flat-allreduce")),
                        "teacher_head": "computed (unused by the loss, as in the reference)", "final_loss": last_loss},
-            "roofline": {"bound": "mfma", "kernel": kname,
+            "roofline": {"bound": "mfma", "kernel": kname + "; " + arith,
                          "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": traffic, "algorithmic_tflops": round(algorithmic, 3),
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "flops": "algorithmic (SURVEY 8(d)): dense 2*k*k*Cin*Cout*rows, sparse 2*pairs*Cin*Cout",
+                         "algorithmic_flops_per_launch": round(sum(flops) / max(n_launch, 1)),
+                         "mfma_issue_frac": round(issue * achieved / peak, 4),
                          "isolated": None if iso is None else {
                              "note": "same launches in 2 extra steps with the stream overlaps (teacher || student, wgrad || dgrad) off: in the timed region a "
                                      "launch shares the GPU with the other streams' kernels, which lengthens it while shortening the step",
-                             "avg_launch_ms": round(iso[0], 4), "achieved": round(iso[1] * (3.0 if b3 else 1.0), 3),
-                             "frac": round(iso[1] * (3.0 if b3 else 1.0) / peak, 4)},
+                             "avg_launch_ms": round(iso[0], 4), "achieved": round(iso[1], 3), "frac": round(iso[1] / peak, 4)},
                          "launches_per_step": n_launch // max(prof_steps, 1), "measured": roofline_note, "avg_launch_ms": round(avg_ms, 4),
                          "ms_per_step_by_kernel": {str(k): round(v / prof_steps, 3) for k, v in sorted(by_kern.items(), key=lambda kv: -kv[1])},
-                         "time_share_of_step": round(sum(kernel_ms) / prof_steps / (dt / args.steps * 1e3), 4),
-                         "all_mfma_conv_fwd_dgrad_share_of_step": round(sum(all_ms) / prof_steps / (dt / args.steps * 1e3), 4)},
+                         "algorithmic_tflops_by_kernel": {str(k): round(fl_kern[k] / (by_kern[k] * 1e-3) / 1e12, 1) for k in sorted(by_kern, key=lambda k: -by_kern[k])},
+                         "time_share_of_step": round(sum(kernel_ms) / prof_steps / step_ms, 4),
+                         "all_mfma_conv_share_of_step": round(sum(all_ms) / prof_steps / step_ms, 4)},
         }
         # HBM side of the metric ("HBM GB/s vs peak"): the streaming train-mode BatchNorm forward (normalise + affine + residual + ReLU,
         # one launch per layer), algorithmic bytes = x (+ residual) read once, y written once; launches of >= 16 MB only (smaller maps

@@ -43,3 +43,13 @@ def forward_train(state, batch, pc_range, voxel_size, grid_size, run_teacher_hea
                       radar_b3=rb3, radar_2d=r2d, preds=preds, targets=targets,
                       loss_feature=loss_feat, loss_rpn=loss_rpn))
     return loss_feat + loss_rpn, tb, inter
+
+
+def forward_radar_only(state, radar_points, batch_size, pc_range, voxel_size, grid_size):
+    """BASELINE configs[0] (C1): the radar student alone in eval mode -- radar VFE -> SparseEnc(+conv5) -> CMA + DenseEnc -> CenterHead
+    forward (the module chain radar_distill_val.yaml builds: detectors/pillarnet.py:28-46 over the four radar_* modules)."""
+    rv = vfe.dynamic_pillar_vfe(radar_points, state, "radar_vfe.", pc_range, voxel_size, grid_size, training=False)
+    rb3 = sparse.pillar_res18_backbone(rv["pillar_features"], rv["pillar_coords"].numpy(), batch_size, grid_size, state, "radar_backbone_3d.",
+                                       training=False)
+    r2d = bev.radar_distill_forward(rb3["x_conv4"], rb3["x_conv5"], state, "radar_backbone_2d.", training=False)
+    return head.center_head_forward(r2d["radar_spatial_features_2d"], state, "radar_dense_head.", len(HEADS), False)

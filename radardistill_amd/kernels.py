@@ -351,8 +351,13 @@ def conv_wgrad(x, grad_out, taps, ix, nbr_keepalive=None, in_split=False, go_spl
             if pairs is None:
                 pairs = (nbr_keepalive >= 0).sum()
                 nbr_keepalive._rd_pairs = pairs
+        # which instantiation conv_wgrad_impl (conv.hip) launches: the Cin tile is 128 for Cin >= 128 in bf16x3 mode; in exact fp32
+        # only when that leaves >= 32 (tap, tile) pairs
+        b3 = get_conv_math() == "bf16x3" and Cout >= 64 and Cin >= 64
+        wide = Cin >= 128 if b3 else (Cin >= 128 and Cout >= 64 and taps * ((Cout + 127) // 128) * ((Cin + 127) // 128) >= 32)
+        tag = ("wgrad_b3_" if b3 else "wgrad_f32_") + ("deform_" if ix.mode == 3 else "") + ("128" if wide else "64")
         WGRAD_PROFILE.append((e0, e1, pairs, 2.0 * Cin * Cout if pairs is not None else 2.0 * out_rows * taps * Cin * Cout,
-                              (in_rows, Cin, Cout, taps, ix.mode)))
+                              (in_rows, Cin, Cout, taps, ix.mode, tag)))
     return gw
 
 
