@@ -27,6 +27,14 @@ extern "C" {
 
 const char *rd_last_error(void);
 int rd_abi_version(void);
+/* Test switch (process-wide, default 0).  1 = every floating-point reduction of the library runs in one fixed order: sums that are
+ * normally combined from per-block partials with fp32 atomics (BatchNorm statistics, weight-gradient row chunks, column sums, GRN /
+ * VFE / DCN scatter sums) get exactly one contributing block per output element or an ordered variant.  Results are then
+ * bit-identical from run to run and independent of stream placement; launches are much slower.  The reference has no such switch
+ * (cuDNN / spconv / torch_scatter atomics are non-deterministic there too); it exists so that tests can separate scheduling
+ * defects from summation-order noise. */
+int rd_set_deterministic(int on);
+int rd_get_deterministic(void);
 /* 1 if a gfx950 device is usable, 0 otherwise (never throws). */
 int rd_device_ok(void);
 

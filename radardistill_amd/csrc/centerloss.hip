@@ -1,14 +1,16 @@
-// CenterHead training loss, all task heads, forward and backward in five launches.
+// CenterHead training loss, all task heads, forward and backward in six launches.  Every sum runs in a fixed
+// order (no floating-point atomics): loss values and gradients are bit-identical from run to run.
 // Replaces the reference's per-head Python loop (pcdet/models/dense_heads/radar_center_head.py:258-330: FocalLossCenterNet
 // utils/loss_utils.py:169-200 neg_loss_cornernet, RegLossCenterNet :203-250 _reg_loss, the decode of every cell :300-314, IouLoss
 // :618-640 on boxes_aligned_iou3d_gpu, IouRegLoss :643-662 on centernet_utils.bbox3d_overlaps_diou :462-497) -- ~100 small ATen
 // launches forward and ~250 backward, i.e. ~4 ms of HOST time per 30 ms step -- by
-//   k_cl_focal      heat maps: clamp(sigmoid) focal terms, per-channel sums (LDS then global atomics)
+//   k_cl_focal      heat maps: clamp(sigmoid) focal terms, per-channel sums (one workgroup per channel, ordered tree)
 //   k_cl_slots      one lane per (head, sample, object slot): gather the 11 regression channels at the object's cell, L1 terms,
 //                   box decode, rotated aligned IoU target, axis-aligned DIoU, and the per-slot GRADIENTS of all three terms
+//   k_cl_head_sums  the per-slot loss terms of each head added in slot order
 //   k_cl_finalize   per-head normalisation, the four per-head losses, the total, the backward scale factors
 //   k_cl_bwd_dense  d loss / d maps: focal gradient in the heat-map columns, zero elsewhere
-//   k_cl_bwd_slots  scatter-add of the per-slot gradients (several objects may share a cell)
+//   k_cl_bwd_slots  per-slot gradients added into their cells (several objects may share a cell: its first slot adds them all)
 // Maps are the batched-branch output: ONE channels-last (B, H, W, NO) tensor, columns [hm | center | center_z | dim | rot | vel | iou],
 // heads inner (column = base + head * width + j).  Arithmetic follows the torch expressions term by term (fp32).
 #include <algorithm>
@@ -20,37 +22,42 @@ namespace {
 
 constexpr int CL_ACC = 13;   // per head: 10 L1 code sums, IoU-loss sum, DIoU-loss sum, positives
 
+// One workgroup per heat-map channel: thread-private sums over its strided pixels, then a fixed-order tree -- every run adds the same
+// terms in the same order (the first version combined all threads through LDS atomics: non-deterministic last bits in the loss).
 __global__ __launch_bounds__(256) void k_cl_focal(const rd_center_loss_cfg c, const float *__restrict__ maps, const float *__restrict__ gt,
                                                   float *__restrict__ acc_ch) {
-    __shared__ float s_sum[16], s_pos[16];
-    if (threadIdx.x < 16) s_sum[threadIdx.x] = s_pos[threadIdx.x] = 0.f;
-    __syncthreads();
+    __shared__ float s_sum[256], s_pos[256];
+    const int ch = blockIdx.x;
     const int64_t n_pix = (int64_t)c.B * c.H * c.W;
     const int HW = c.H * c.W;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_pix * c.n_ch; e += (int64_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(e % c.n_ch);
-        const int64_t pix = e / c.n_ch;
+    float sum = 0.f, pos = 0.f;
+    for (int64_t pix = threadIdx.x; pix < n_pix; pix += 256) {
         const int b = (int)(pix / HW), cell = (int)(pix - (int64_t)b * HW);
         const float x = maps[pix * c.NO + c.hm_c0 + ch];
         const float g = gt[((int64_t)b * c.n_ch + ch) * HW + cell];
         const float s = 1.f / (1.f + expf(-x));
         const float hm = fminf(fmaxf(s, 1e-4f), 1.f - 1e-4f);
-        float term;
         if (g == 1.f) {
-            term = logf(hm) * ((1.f - hm) * (1.f - hm));
-            atomicAdd(&s_pos[ch], 1.f);
+            sum += logf(hm) * ((1.f - hm) * (1.f - hm));
+            pos += 1.f;
         } else if (g < 1.f) {
             const float q = 1.f - g, q2 = q * q;
-            term = logf(1.f - hm) * (hm * hm) * (q2 * q2);
-        } else {
-            term = 0.f;
+            sum += logf(1.f - hm) * (hm * hm) * (q2 * q2);
         }
-        atomicAdd(&s_sum[ch], term);
     }
+    s_sum[threadIdx.x] = sum;
+    s_pos[threadIdx.x] = pos;
     __syncthreads();
-    if ((int)threadIdx.x < c.n_ch) {
-        atomicAdd(&acc_ch[threadIdx.x], s_sum[threadIdx.x]);
-        atomicAdd(&acc_ch[16 + threadIdx.x], s_pos[threadIdx.x]);
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) {
+            s_sum[threadIdx.x] += s_sum[threadIdx.x + d];
+            s_pos[threadIdx.x] += s_pos[threadIdx.x + d];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        acc_ch[ch] = s_sum[0];
+        acc_ch[16 + ch] = s_pos[0];
     }
 }
 
@@ -106,11 +113,8 @@ __device__ inline Diou diou_with_grad(const float *p, const float *q) {
 // slot_grad[s][17]: [0..9] d L1 / d code (code weight applied), [10..15] d (1 - diou) / d (center0, center1, center_z, dim0..2), [16] d iou term / d iou
 __global__ __launch_bounds__(256) void k_cl_slots(const rd_center_loss_cfg c, const float *__restrict__ maps, const int64_t *__restrict__ inds,
                                                   const int64_t *__restrict__ masks, const float *__restrict__ tgt_boxes, int tgt_dim,
-                                                  const float *__restrict__ gt_box, int gt_dim, float *__restrict__ acc_head,
+                                                  const float *__restrict__ gt_box, int gt_dim, float *__restrict__ slot_terms,
                                                   float *__restrict__ slot_grad) {
-    __shared__ float s_acc[8 * CL_ACC];
-    for (int i = threadIdx.x; i < 8 * CL_ACC; i += blockDim.x) s_acc[i] = 0.f;
-    __syncthreads();
     const int n_slots = c.n_heads * c.B * c.K;
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s < n_slots) {
@@ -130,19 +134,21 @@ __global__ __launch_bounds__(256) void k_cl_slots(const rd_center_loss_cfg c, co
         pred[6] = px[c.c0_rot + h * 2]; pred[7] = px[c.c0_rot + h * 2 + 1];
         pred[8] = px[c.c0_vel + h * 2]; pred[9] = px[c.c0_vel + h * 2 + 1];
         ioup = px[c.c0_iou + h];
-        float *acc = s_acc + h * CL_ACC;
+        float *acc = slot_terms + (int64_t)s * CL_ACC;      // this slot's 13 loss terms; k_cl_finalize adds the slots in slot order
+#pragma unroll
+        for (int j = 0; j < CL_ACC; ++j) acc[j] = 0.f;
         // ---- L1 on the 10 regression codes: |pred*m - tgt*m|, m = mask * !isnan(tgt)
 #pragma unroll
         for (int j = 0; j < 10; ++j) {
             const float t = tgt_boxes[(int64_t)s * tgt_dim + j];
             const float m = mf * (isnan(t) ? 0.f : 1.f);
             const float d = pred[j] * m - t * m;
-            atomicAdd(&acc[j], fabsf(d));
+            acc[j] = fabsf(d);
             sg[j] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * m * c.code_w[j];
         }
         float gd[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gi = 0.f;
         if (valid) {
-            atomicAdd(&acc[12], 1.f);
+            acc[12] = 1.f;
             // ---- decode this cell (radar_center_head.py:300-314; the int() truncation of the range origin is in c.org_*)
             const int cy = (int)(cell / c.W), cx = (int)(cell - (int64_t)cy * c.W);
             float pb[7], gb[7];
@@ -164,11 +170,11 @@ __global__ __launch_bounds__(256) void k_cl_slots(const rd_center_loss_cfg c, co
             const float o3 = bev * oh;
             const float iou = o3 / fmaxf(pb[3] * pb[4] * pb[5] + gb[3] * gb[4] * gb[5] - o3, 1e-6f);
             const float di = ioup - (2.f * iou - 1.f);
-            atomicAdd(&acc[10], fabsf(di));
+            acc[10] = fabsf(di);
             gi = di > 0.f ? 1.f : (di < 0.f ? -1.f : 0.f);
             // ---- DIoU regression loss: 1 - diou
             const Diou dd = diou_with_grad(pb, gb);
-            atomicAdd(&acc[11], 1.f - dd.val);
+            acc[11] = 1.f - dd.val;
             gd[0] = -dd.g[0] * (c.stride * c.vs_x);
             gd[1] = -dd.g[1] * (c.stride * c.vs_y);
             gd[2] = -dd.g[2];
@@ -179,9 +185,26 @@ __global__ __launch_bounds__(256) void k_cl_slots(const rd_center_loss_cfg c, co
         for (int j = 0; j < 6; ++j) sg[10 + j] = gd[j];
         sg[16] = gi;
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < c.n_heads * CL_ACC; i += blockDim.x)
-        if (s_acc[i] != 0.f) atomicAdd(&acc_head[i], s_acc[i]);
+}
+
+// acc_head[h][13] = sum over the (sample, slot) pairs of head h of the per-slot terms: one workgroup per head, thread-private sums
+// over strided slots + a fixed-order tree.
+__global__ __launch_bounds__(256) void k_cl_head_sums(const rd_center_loss_cfg c, const float *__restrict__ slot_terms, float *__restrict__ acc_head) {
+    __shared__ float s_red[256];
+    const int h = blockIdx.x, per_head = c.B * c.K;
+    const float *base = slot_terms + (int64_t)h * per_head * CL_ACC;
+    for (int q = 0; q < CL_ACC; ++q) {
+        float v = 0.f;
+        for (int i = threadIdx.x; i < per_head; i += 256) v += base[(int64_t)i * CL_ACC + q];
+        s_red[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 128; d >= 1; d >>= 1) {
+            if ((int)threadIdx.x < d) s_red[threadIdx.x] += s_red[threadIdx.x + d];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) acc_head[h * CL_ACC + q] = s_red[0];
+        __syncthreads();
+    }
 }
 
 // out[h*4 + {0,1,2,3}] = hm / loc / iou / iou_reg loss of head h, out[4*nh] = total; scale[h*4 + {0..3}] = backward factors
@@ -243,30 +266,46 @@ __global__ __launch_bounds__(256) void k_cl_bwd_dense(const rd_center_loss_cfg c
     }
 }
 
+// Several objects of one head and sample may share a cell.  The FIRST valid slot of a cell owns it: it adds the gradients of all
+// later slots of the same cell in slot order and writes once (plain adds onto k_cl_bwd_dense's output) -- no atomics, one fixed order.
 __global__ __launch_bounds__(256) void k_cl_bwd_slots(const rd_center_loss_cfg c, const int64_t *__restrict__ inds, const int64_t *__restrict__ masks,
                                                       const float *__restrict__ slot_grad, const float *__restrict__ scale,
                                                       const float *__restrict__ g_up, float *__restrict__ grad) {
     const int n_slots = c.n_heads * c.B * c.K;
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_slots || masks[s] == 0) return;
-    const int h = s / (c.B * c.K), b = (s / c.K) % c.B;
+    const int h = s / (c.B * c.K), b = (s / c.K) % c.B, k = s % c.K;
     const int64_t cell = inds[s];
     if (cell < 0 || cell >= (int64_t)c.H * c.W) return;
+    const int s0 = s - k;                                   // first slot of this (head, sample)
+    for (int q = 0; q < k; ++q)
+        if (masks[s0 + q] != 0 && inds[s0 + q] == cell) return;          // an earlier slot owns the cell
     const float up = g_up[0];
     const float s1 = up * scale[h * 4 + 1], si = up * scale[h * 4 + 2], sd = up * scale[h * 4 + 3];
-    const float *sg = slot_grad + (int64_t)s * 17;
+    float add[11];
+#pragma unroll
+    for (int j = 0; j < 11; ++j) add[j] = 0.f;
+    for (int q = k; q < c.K; ++q) {
+        if (masks[s0 + q] == 0 || inds[s0 + q] != cell) continue;
+        const float *sg = slot_grad + (int64_t)(s0 + q) * 17;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) add[j] += s1 * sg[j] + sd * sg[10 + j];
+#pragma unroll
+        for (int j = 6; j < 10; ++j) add[j] += s1 * sg[j];
+        add[10] += si * sg[16];
+    }
     float *px = grad + ((int64_t)b * c.H * c.W + cell) * c.NO;
-    atomicAdd(&px[c.c0_center + h * 2], s1 * sg[0] + sd * sg[10]);
-    atomicAdd(&px[c.c0_center + h * 2 + 1], s1 * sg[1] + sd * sg[11]);
-    atomicAdd(&px[c.c0_z + h], s1 * sg[2] + sd * sg[12]);
-    atomicAdd(&px[c.c0_dim + h * 3], s1 * sg[3] + sd * sg[13]);
-    atomicAdd(&px[c.c0_dim + h * 3 + 1], s1 * sg[4] + sd * sg[14]);
-    atomicAdd(&px[c.c0_dim + h * 3 + 2], s1 * sg[5] + sd * sg[15]);
-    atomicAdd(&px[c.c0_rot + h * 2], s1 * sg[6]);
-    atomicAdd(&px[c.c0_rot + h * 2 + 1], s1 * sg[7]);
-    atomicAdd(&px[c.c0_vel + h * 2], s1 * sg[8]);
-    atomicAdd(&px[c.c0_vel + h * 2 + 1], s1 * sg[9]);
-    atomicAdd(&px[c.c0_iou + h], si * sg[16]);
+    px[c.c0_center + h * 2] += add[0];
+    px[c.c0_center + h * 2 + 1] += add[1];
+    px[c.c0_z + h] += add[2];
+    px[c.c0_dim + h * 3] += add[3];
+    px[c.c0_dim + h * 3 + 1] += add[4];
+    px[c.c0_dim + h * 3 + 2] += add[5];
+    px[c.c0_rot + h * 2] += add[6];
+    px[c.c0_rot + h * 2 + 1] += add[7];
+    px[c.c0_vel + h * 2] += add[8];
+    px[c.c0_vel + h * 2 + 1] += add[9];
+    px[c.c0_iou + h] += add[10];
 }
 
 int check_cfg(const rd_center_loss_cfg *c, const char *who) {
@@ -286,7 +325,7 @@ int check_cfg(const rd_center_loss_cfg *c, const char *who) {
 
 extern "C" int64_t rd_center_loss_ws_floats(const rd_center_loss_cfg *cfg) {
     if (!cfg) return 0;
-    return 32 + 8 * CL_ACC + (int64_t)cfg->n_heads * cfg->B * cfg->K * 17;
+    return 32 + 8 * CL_ACC + (int64_t)cfg->n_heads * cfg->B * cfg->K * (17 + CL_ACC);
 }
 
 extern "C" int rd_center_loss_fwd(const rd_center_loss_cfg *cfg, const float *maps, const float *heatmaps, const int64_t *inds,
@@ -296,12 +335,11 @@ extern "C" int rd_center_loss_fwd(const rd_center_loss_cfg *cfg, const float *ma
     if (rc) return rc;
     RD_REQUIRE(target_dim >= 10 && gt_dim >= 7, "rd_center_loss_fwd: target boxes need >= 10 codes, gt boxes >= 7 values");
     hipStream_t st = S(stream);
-    float *acc_ch = ws, *acc_head = ws + 32, *slot_grad = ws + 32 + 8 * CL_ACC;
-    RD_HIP(hipMemsetAsync(ws, 0, (32 + 8 * CL_ACC) * sizeof(float), st));
-    const int64_t n_el = (int64_t)cfg->B * cfg->H * cfg->W * cfg->n_ch;
-    k_cl_focal<<<(unsigned)std::min<int64_t>(cdiv(n_el, 256), 2048), 256, 0, st>>>(*cfg, maps, heatmaps, acc_ch);
     const int n_slots = cfg->n_heads * cfg->B * cfg->K;
-    k_cl_slots<<<(unsigned)cdiv(n_slots, 256), 256, 0, st>>>(*cfg, maps, inds, masks, target_boxes, target_dim, gt_box, gt_dim, acc_head, slot_grad);
+    float *acc_ch = ws, *acc_head = ws + 32, *slot_grad = ws + 32 + 8 * CL_ACC, *slot_terms = slot_grad + (int64_t)n_slots * 17;
+    k_cl_focal<<<(unsigned)cfg->n_ch, 256, 0, st>>>(*cfg, maps, heatmaps, acc_ch);
+    k_cl_slots<<<(unsigned)cdiv(n_slots, 256), 256, 0, st>>>(*cfg, maps, inds, masks, target_boxes, target_dim, gt_box, gt_dim, slot_terms, slot_grad);
+    k_cl_head_sums<<<(unsigned)cfg->n_heads, 256, 0, st>>>(*cfg, slot_terms, acc_head);
     k_cl_finalize<<<1, 64, 0, st>>>(*cfg, acc_ch, acc_head, out, scale);
     return check_launch("rd_center_loss_fwd");
 }

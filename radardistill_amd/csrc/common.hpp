@@ -10,6 +10,12 @@ namespace rd {
 
 void set_error(const char *fmt, ...);
 
+// rd_set_deterministic (test switch): every floating-point reduction runs in one fixed order -- reductions that normally combine
+// per-block partial sums with fp32 atomics (BatchNorm statistics, weight-gradient row chunks, column sums, ...) are launched so that
+// each output element has exactly ONE contributing block, or run their own ordered variant.  Results then do not depend on how
+// kernels of different streams interleave; speed is not a goal of this mode.
+extern int g_deterministic;
+
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -286,6 +286,15 @@ static int conv_fwd_impl(const float *in, int in_rows, int Cin, const float *wei
     int rc = validate_index(idx, taps, in_rows, out_rows, "rd_conv_fwd");
     if (rc) return rc;
     if (out_rows == 0) return RD_OK;
+    if (g_deterministic && stats) {
+        // fixed summation order: the column sums come from their own single-block pass over the finished output instead of the
+        // epilogue's per-tile partials + atomics
+        rc = conv_fwd_impl(in, in_rows, Cin, weight_k, taps, bias, out, out_rows, Cout, idx, scale, shift, residual, relu, nullptr, in_split,
+                           w_split, stream);
+        if (rc) return rc;
+        RD_REQUIRE(!scale && !shift && !residual && !relu, "rd_conv_fwd: statistics are taken from the raw convolution output");
+        return rd_bn_stats(out, out_rows, Cout, stats, stream);
+    }
     ConvArgs a{in, in_rows, Cin, weight_k, taps, bias, out, out_rows, Cout, *idx, scale, shift, residual, relu, stats};
     a.in_split = in_split;
     a.w_split = w_split;
@@ -614,6 +623,7 @@ static int conv_wgrad_impl(const float *in, int in_rows, int Cin, const float *g
             if (cost < best) { best = cost; chunks = c; }
         }
     }
+    if (g_deterministic) chunks = 1;     // every (tap, tile) accumulates all rows in one block: no atomics between row chunks
     int rows_per_block = (int)(cdiv(cdiv(out_rows, chunks), WG_KB) * WG_KB);
     chunks = cdiv(out_rows, rows_per_block);
     hipStream_t st = S(stream);

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_grn_reduce(const float *__restrict__ x,
     const int gc = blockIdx.y * GRN_COLS + c;
     if (gc < C) {
         atomicAdd(&acc1[(int64_t)b * C + gc], red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-        if (MODE == 1) atomicAdd(&acc2[gc], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        if (MODE == 1 && acc2) atomicAdd(&acc2[gc], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
     }
 }
 
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void k_grn_apply(const float *__restrict__ a, 
         } else {
             const float Sv = S[(int64_t)b * C + c];
             tab[C + c] = G > 0.f ? (gamma[c] * Sv / m - s_T / ((float)C * m * m)) / G : 0.f;
-            if (blockIdx.x == 0) atomicAdd(&dgamma[c], N * Sv);
+            if (blockIdx.x == 0 && dgamma) atomicAdd(&dgamma[c], N * Sv);
         }
     }
     __syncthreads();
@@ -131,6 +131,33 @@ __global__ __launch_bounds__(256) void k_grn_apply(const float *__restrict__ a, 
     }
 }
 
+// rd_set_deterministic(1): the two sums over SAMPLES (dbeta_c = sum g, dgamma_c = sum_b N_bc S_bc) in sample order, one block.
+__global__ __launch_bounds__(256) void k_grn_param_grads_ordered(const float *__restrict__ g, const float *__restrict__ ssq, const float *__restrict__ S,
+                                                                 int B, int64_t hw, int C, float *dgamma, float *dbeta) {
+    __shared__ float s_red[256];
+    __shared__ float s_m;
+    const int tid = threadIdx.x;
+    for (int b = 0; b < B; ++b) {
+        float part = 0.f;
+        for (int c = tid; c < C; c += 256) part += sqrtf(ssq[(int64_t)b * C + c]);
+        s_red[tid] = part;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) s_red[tid] += s_red[tid + s];
+            __syncthreads();
+        }
+        if (tid == 0) s_m = s_red[0] / (float)C + 1e-6f;
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) dgamma[c] += sqrtf(ssq[(int64_t)b * C + c]) / s_m * S[(int64_t)b * C + c];
+        __syncthreads();
+    }
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int64_t r = 0; r < (int64_t)B * hw; ++r) s += g[r * C + c];
+        dbeta[c] = s;
+    }
+}
+
 static int grn_check(int B, int64_t hw, int C, const char *who) {
     RD_REQUIRE(B >= 1 && B <= 65535 && hw >= 1 && C >= 4 && C % 4 == 0 && C <= 8192, "%s: bad sizes (C multiple of 4, <= 8192)", who);
     return RD_OK;
@@ -142,7 +169,7 @@ extern "C" int rd_gelu_grn_fwd(const float *z, int B, int64_t hw, int C, const f
     if (rc) return rc;
     hipStream_t st = S(stream);
     RD_HIP(hipMemsetAsync(ssq, 0, (size_t)B * C * 4, st));
-    const int rb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(hw, 64), 64));
+    const int rb = g_deterministic ? 1 : (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(hw, 64), 64));
     k_grn_reduce<0><<<dim3(rb, (unsigned)cdiv(C, GRN_COLS), B), 256, 0, st>>>(z, nullptr, hw, C, a, ssq, nullptr);
     const int ab = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(hw * C / 4, 256 * 8), 256));
     k_grn_apply<0><<<dim3(ab, B), 256, (size_t)2 * C * 4, st>>>(a, nullptr, nullptr, ssq, nullptr, gamma, beta, hw, C, out, nullptr);
@@ -157,9 +184,11 @@ extern "C" int rd_gelu_grn_bwd(const float *grad_out, const float *a, const floa
     RD_HIP(hipMemsetAsync(S_ws, 0, (size_t)B * C * 4, st));
     RD_HIP(hipMemsetAsync(grad_gamma, 0, (size_t)C * 4, st));
     RD_HIP(hipMemsetAsync(grad_beta, 0, (size_t)C * 4, st));
-    const int rb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(hw, 64), 64));
-    k_grn_reduce<1><<<dim3(rb, (unsigned)cdiv(C, GRN_COLS), B), 256, 0, st>>>(grad_out, a, hw, C, nullptr, S_ws, grad_beta);
+    const bool det = g_deterministic != 0;
+    const int rb = det ? 1 : (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(hw, 64), 64));
+    k_grn_reduce<1><<<dim3(rb, (unsigned)cdiv(C, GRN_COLS), B), 256, 0, st>>>(grad_out, a, hw, C, nullptr, S_ws, det ? nullptr : grad_beta);
     const int ab = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(hw * C / 4, 256 * 8), 256));
-    k_grn_apply<1><<<dim3(ab, B), 256, (size_t)2 * C * 4, st>>>(a, grad_out, z, ssq, S_ws, gamma, nullptr, hw, C, grad_z, grad_gamma);
+    k_grn_apply<1><<<dim3(ab, B), 256, (size_t)2 * C * 4, st>>>(a, grad_out, z, ssq, S_ws, gamma, nullptr, hw, C, grad_z, det ? nullptr : grad_gamma);
+    if (det) k_grn_param_grads_ordered<<<1, 256, 0, st>>>(grad_out, ssq, S_ws, B, hw, C, grad_gamma, grad_beta);
     return check_launch("rd_gelu_grn_bwd");
 }

@@ -89,50 +89,68 @@ extern "C" int rd_dcn_prep(const float *offset, int off_stride, const float *mas
 }
 
 // One wave per (output pixel j, tap t); lanes sweep the C channels, lane l taking l, l + 64, ...
+// ORDERED (rd_set_deterministic(1)): ONE workgroup walks all (pixel, tap) pairs in order; wave w owns the channels w*64 + lane
+// (+ 64 * waves ...), so every grad_x element is updated by one lane in pair order with plain adds, and the per-pair sums over
+// channels are combined across the waves in wave order through LDS.
+template <bool ORDERED>
 __global__ __launch_bounds__(256) void k_dcn_bwd_data(const float *__restrict__ x, int C, const float *__restrict__ colgrad,
                                                       const float *__restrict__ offset, int off_stride, const float *__restrict__ mask,
                                                       int mask_stride, int sig, DcnGeom g, int n_rows, int taps, float *grad_x,
                                                       float *grad_offset, int goff_stride, float *grad_mask, int gmask_stride) {
-    const int lane = threadIdx.x & 63;
-    const int64_t pair = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (pair >= (int64_t)n_rows * taps) return;
-    const int j = (int)(pair / taps), t = (int)(pair % taps);
-    const float oh = offset[(int64_t)j * off_stride + 2 * t], ow = offset[(int64_t)j * off_stride + 2 * t + 1];
-    float mraw = mask[(int64_t)j * mask_stride + t];
-    const float m = sig ? sigmoidf_(mraw) : mraw;
-    const Sample s = dcn_sample(g, j, t, oh, ow);
-    float dmask = 0.f, dh = 0.f, dw = 0.f;
-    if (s.inside) {
-        const float hh = 1.f - s.lh, hw = 1.f - s.lw;
-        const float *gc = colgrad + ((int64_t)j * taps + t) * C;
-        // lane l handles channels l, l + 64, ...: every atomic instruction of the wave covers 256 CONTIGUOUS bytes (the memory-side
-        // float atomics run ~4x slower when a wave's addresses are strided, which the float4-per-lane layout of round 1 made them)
-        for (int c = lane; c < C; c += 64) {
-            const float gv = gc[c];
-            float v[4];
+    __shared__ float s_part[4][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const int64_t n_pairs = (int64_t)n_rows * taps;
+    const int64_t first = ORDERED ? 0 : (int64_t)blockIdx.x * n_waves + wave;
+    const int64_t last = ORDERED ? n_pairs : min(n_pairs, first + 1);
+    for (int64_t pair = first; pair < last; ++pair) {
+        const int j = (int)(pair / taps), t = (int)(pair % taps);
+        const float oh = offset[(int64_t)j * off_stride + 2 * t], ow = offset[(int64_t)j * off_stride + 2 * t + 1];
+        float mraw = mask[(int64_t)j * mask_stride + t];
+        const float m = sig ? sigmoidf_(mraw) : mraw;
+        const Sample s = dcn_sample(g, j, t, oh, ow);
+        float dmask = 0.f, dh = 0.f, dw = 0.f;
+        if (s.inside) {
+            const float hh = 1.f - s.lh, hw = 1.f - s.lw;
+            const float *gc = colgrad + ((int64_t)j * taps + t) * C;
+            // lane l handles channels l, l + 64, ...: every atomic instruction of the wave covers 256 CONTIGUOUS bytes (the memory-side
+            // float atomics run ~4x slower when a wave's addresses are strided, which the float4-per-lane layout of round 1 made them)
+            for (int c = ORDERED ? wave * 64 + lane : lane; c < C; c += ORDERED ? 64 * n_waves : 64) {
+                const float gv = gc[c];
+                float v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = s.idx[k] >= 0 ? x[(int64_t)s.idx[k] * C + c] : 0.f;
-            const float val = s.w[0] * v[0] + s.w[1] * v[1] + s.w[2] * v[2] + s.w[3] * v[3];
-            dmask += gv * val;
-            // mdmcn_get_coordinate_weight (modulated_deform_im2col_cuda.cuh:84-125)
-            dh += gv * (-hw * v[0] - s.lw * v[1] + hw * v[2] + s.lw * v[3]);
-            dw += gv * (-hh * v[0] + hh * v[1] - s.lh * v[2] + s.lh * v[3]);
-            // input gradient: grad_x[corner] += mask * corner weight * column gradient  (col2im, :196-254)
+                for (int k = 0; k < 4; ++k) v[k] = s.idx[k] >= 0 ? x[(int64_t)s.idx[k] * C + c] : 0.f;
+                const float val = s.w[0] * v[0] + s.w[1] * v[1] + s.w[2] * v[2] + s.w[3] * v[3];
+                dmask += gv * val;
+                // mdmcn_get_coordinate_weight (modulated_deform_im2col_cuda.cuh:84-125)
+                dh += gv * (-hw * v[0] - s.lw * v[1] + hw * v[2] + s.lw * v[3]);
+                dw += gv * (-hh * v[0] + hh * v[1] - s.lh * v[2] + s.lh * v[3]);
+                // input gradient: grad_x[corner] += mask * corner weight * column gradient  (col2im, :196-254)
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (s.idx[k] >= 0) atomicAdd(grad_x + (int64_t)s.idx[k] * C + c, m * s.w[k] * gv);
+                for (int k = 0; k < 4; ++k)
+                    if (s.idx[k] >= 0) {
+                        if (ORDERED) grad_x[(int64_t)s.idx[k] * C + c] += m * s.w[k] * gv;
+                        else atomicAdd(grad_x + (int64_t)s.idx[k] * C + c, m * s.w[k] * gv);
+                    }
+            }
         }
-    }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        dmask += __shfl_xor(dmask, d, 64);
-        dh += __shfl_xor(dh, d, 64);
-        dw += __shfl_xor(dw, d, 64);
-    }
-    if (lane == 0) {
-        grad_offset[(int64_t)j * goff_stride + 2 * t] = dh * m;
-        grad_offset[(int64_t)j * goff_stride + 2 * t + 1] = dw * m;
-        grad_mask[(int64_t)j * gmask_stride + t] = sig ? dmask * m * (1.f - m) : dmask;
+        for (int d = 32; d >= 1; d >>= 1) {
+            dmask += __shfl_xor(dmask, d, 64);
+            dh += __shfl_xor(dh, d, 64);
+            dw += __shfl_xor(dw, d, 64);
+        }
+        if (ORDERED) {
+            if (lane == 0) { s_part[wave][0] = dmask; s_part[wave][1] = dh; s_part[wave][2] = dw; }
+            __syncthreads();
+            dmask = dh = dw = 0.f;
+            for (int w = 0; w < n_waves; ++w) { dmask += s_part[w][0]; dh += s_part[w][1]; dw += s_part[w][2]; }
+            __syncthreads();
+        }
+        if (lane == 0 && (!ORDERED || wave == 0)) {
+            grad_offset[(int64_t)j * goff_stride + 2 * t] = dh * m;
+            grad_offset[(int64_t)j * goff_stride + 2 * t + 1] = dw * m;
+            grad_mask[(int64_t)j * gmask_stride + t] = sig ? dmask * m * (1.f - m) : dmask;
+        }
     }
 }
 
@@ -148,7 +166,11 @@ extern "C" int rd_dcn_bwd_data(const float *x, int C, const float *colgrad, cons
     RD_HIP(hipMemsetAsync(grad_x, 0, (size_t)B * H * W * C * 4, st));
     const int64_t pairs = (int64_t)B * Ho * Wo * taps;
     if (pairs == 0) return RD_OK;
-    k_dcn_bwd_data<<<cdiv(pairs, 4), 256, 0, st>>>(x, C, colgrad, offset, off_stride, mask, mask_stride, apply_sigmoid, g, B * Ho * Wo, taps,
-                                                   grad_x, grad_offset, goff_stride, grad_mask, gmask_stride);
+    if (g_deterministic)
+        k_dcn_bwd_data<true><<<1, 256, 0, st>>>(x, C, colgrad, offset, off_stride, mask, mask_stride, apply_sigmoid, g, B * Ho * Wo, taps,
+                                                grad_x, grad_offset, goff_stride, grad_mask, gmask_stride);
+    else
+        k_dcn_bwd_data<false><<<cdiv(pairs, 4), 256, 0, st>>>(x, C, colgrad, offset, off_stride, mask, mask_stride, apply_sigmoid, g, B * Ho * Wo,
+                                                              taps, grad_x, grad_offset, goff_stride, grad_mask, gmask_stride);
     return check_launch("rd_dcn_bwd_data");
 }

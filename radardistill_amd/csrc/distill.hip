@@ -79,12 +79,24 @@ __global__ __launch_bounds__(256) void k_afd_fwd(const float *__restrict__ lidar
 
 // sums[2][5] (double accumulate) then out[2][2] = (feature_loss, mask_loss) per map, and coef[2][3] for the backward:
 //   feature = 3e-4 * S_ar / B + 5e-5 * (N_ar / N_ir) * S_ir / B   (NaN when N_ir == 0 and ... exactly as the reference: 0 * inf)
-__global__ void k_afd_final(const float *partial, int n_blocks, float inv_B, float inv_cells, float *out, float *coef) {
+// One wavefront: lane l adds the partials of blocks l, l + 64, ... in double, a butterfly combines the lanes (a fixed order, so the
+// result is deterministic); lanes 0 / 1 then finish map 0 / 1.  (Round 1 had two lanes walk all 1024 x 5 partials serially: 154 us.)
+__global__ __launch_bounds__(64) void k_afd_final(const float *partial, int n_blocks, float inv_B, float inv_cells, float *out, float *coef) {
+    double acc[2 * AFD_Q];
+#pragma unroll
+    for (int i = 0; i < 2 * AFD_Q; ++i) acc[i] = 0.0;
+    for (int b = threadIdx.x; b < n_blocks; b += 64)
+#pragma unroll
+        for (int i = 0; i < 2 * AFD_Q; ++i) acc[i] += (double)partial[(int64_t)b * 2 * AFD_Q + i];
+#pragma unroll
+    for (int i = 0; i < 2 * AFD_Q; ++i)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc[i] += __shfl_xor(acc[i], d, 64);
     const int m = threadIdx.x;
     if (m >= 2) return;
-    double s[AFD_Q] = {0, 0, 0, 0, 0};
-    for (int b = 0; b < n_blocks; ++b)
-        for (int q = 0; q < AFD_Q; ++q) s[q] += (double)partial[((int64_t)b * 2 + m) * AFD_Q + q];
+    double s[AFD_Q];
+#pragma unroll
+    for (int q = 0; q < AFD_Q; ++q) s[q] = m == 0 ? acc[q] : acc[AFD_Q + q];
     const float S_ar = (float)s[0], S_ir = (float)s[1], N_ar = (float)s[2], N_ir = (float)s[3];
     // reference: mask_ir *= N_ar / N_ir (elementwise, so cells with mask 0 give 0 * ratio: NaN if ratio is inf or NaN);
     // loss_ir = sum(mse * mask_ir) / B
@@ -279,12 +291,12 @@ __global__ __launch_bounds__(256) void k_pfd(const float *__restrict__ r1, const
     }
 }
 
-__global__ void k_sum_partials(const float *partial, int n, float scale, float *out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < n; ++i) s += (double)partial[i];
-        out[0] = (float)(s * scale);
-    }
+__global__ __launch_bounds__(64) void k_sum_partials(const float *partial, int n, float scale, float *out) {
+    double s = 0.0;                                        // one wavefront, strided adds + butterfly: fixed order
+    for (int i = threadIdx.x; i < n; i += 64) s += (double)partial[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if (threadIdx.x == 0) out[0] = (float)(s * scale);
 }
 
 extern "C" int rd_pfd_fwd(const float *r1, const float *l1, const float *r2, const float *l2, int64_t rows, int C, const float *gt_hm,

@@ -90,6 +90,7 @@ extern "C" int rd_dwconv_wgrad(const float *in, const float *grad_out, int B, in
     RD_REQUIRE(C % 4 == 0 && K % 2 == 1 && K <= 11, "rd_dwconv_wgrad: bad sizes");
     int64_t n_pix = (int64_t)B * H * W;
     int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(64, cdiv(n_pix, 64)));
+    if (g_deterministic) chunks = 1;
     int ppc = (int)cdiv(n_pix, chunks);
     hipStream_t st = S(stream);
     RD_HIP(hipMemsetAsync(grad_w_tc, 0, (size_t)K * K * C * 4, st));

@@ -16,6 +16,9 @@ void set_error(const char *fmt, ...) {
 
 using namespace rd;
 
+namespace rd { int g_deterministic = 0; }
+extern "C" int rd_set_deterministic(int on) { rd::g_deterministic = on ? 1 : 0; return RD_OK; }
+extern "C" int rd_get_deterministic(void) { return rd::g_deterministic; }
 extern "C" const char *rd_last_error(void) { return rd::g_err; }
 extern "C" int rd_abi_version(void) { return 2; }
 extern "C" int rd_device_ok(void) {

@@ -192,11 +192,12 @@ __global__ __launch_bounds__(256) void k_nconv_dgrad(const NconvArgs a) {
 }
 
 // grad_w[col0 + n][c][t] += sum_p go[p][col0 + n] * y[p + d_t][cin0 + c]   (fp32 atomics combine the bands)
-template <int N>
+// ORDERED (rd_set_deterministic(1)): grid.x == 1, the workgroup walks every (sample, band) itself and the 16 pixel groups are
+// combined in group order -- one contributor per output element, no atomics.
+template <int N, bool ORDERED>
 __device__ __forceinline__ void nconv_wgrad_body(const NconvArgs &a, float *lds, float *g_l, float *red) {
     const int br = blockIdx.y, col0 = a.col_off[br], cin0 = a.cin_off[br];
     const int bands = (a.H + NC_T - 1) / NC_T;
-    const int b = blockIdx.x / bands, y0 = (blockIdx.x % bands) * NC_T;
     const int l16 = threadIdx.x & 15, pg = threadIdx.x >> 4;
     float acc[N][9][4];
 #pragma unroll
@@ -205,33 +206,56 @@ __device__ __forceinline__ void nconv_wgrad_body(const NconvArgs &a, float *lds,
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[n][t][j] = 0.f;
-    f32x4 pre[NC_HP];
-    halo_fetch(a, b, y0, 0, cin0, pre);
-    for (int x0 = 0; x0 < a.W; x0 += NC_T) {
-        halo_store(pre, lds);
-        for (int i = threadIdx.x; i < NC_T * NC_T * N; i += 256) {
-            const int p = i / N, n = i % N;
-            const int gy = y0 + (p >> 3), gx = x0 + (p & 7);
-            g_l[p * NC_MAXN + n] = (gy < a.H && gx < a.W) ? a.go[((int64_t)(b * a.H + gy) * a.W + gx) * a.NO + col0 + n] : 0.f;
+    const int vb0 = ORDERED ? 0 : (int)blockIdx.x, vb1 = ORDERED ? a.B * bands : (int)blockIdx.x + 1;
+    for (int vb = vb0; vb < vb1; ++vb) {
+        const int b = vb / bands, y0 = (vb % bands) * NC_T;
+        f32x4 pre[NC_HP];
+        halo_fetch(a, b, y0, 0, cin0, pre);
+        for (int x0 = 0; x0 < a.W; x0 += NC_T) {
+            halo_store(pre, lds);
+            for (int i = threadIdx.x; i < NC_T * NC_T * N; i += 256) {
+                const int p = i / N, n = i % N;
+                const int gy = y0 + (p >> 3), gx = x0 + (p & 7);
+                g_l[p * NC_MAXN + n] = (gy < a.H && gx < a.W) ? a.go[((int64_t)(b * a.H + gy) * a.W + gx) * a.NO + col0 + n] : 0.f;
+            }
+            __syncthreads();
+            if (x0 + NC_T < a.W) halo_fetch(a, b, y0, x0 + NC_T, cin0, pre);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = pg + 16 * i, py = p >> 3, px = p & 7;
+                float g[N];
+#pragma unroll
+                for (int n = 0; n < N; ++n) g[n] = g_l[p * NC_MAXN + n];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const f32x4 x = *reinterpret_cast<const f32x4 *>(lds + ((py + t / 3) * NC_HALO + px + t % 3) * NC_LDW + 4 * l16);
+#pragma unroll
+                    for (int n = 0; n < N; ++n)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[n][t][j] += g[n] * x[j];
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        if (x0 + NC_T < a.W) halo_fetch(a, b, y0, x0 + NC_T, cin0, pre);
+    }
+    if (ORDERED) {
+        // stage one (n, tap) slice of the 16 pixel groups' accumulators at a time ([pg][64 channels], reusing the halo buffer) and
+        // add them in group order
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int p = pg + 16 * i, py = p >> 3, px = p & 7;
-            float g[N];
-#pragma unroll
-            for (int n = 0; n < N; ++n) g[n] = g_l[p * NC_MAXN + n];
+        for (int n = 0; n < N; ++n)
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const f32x4 x = *reinterpret_cast<const f32x4 *>(lds + ((py + t / 3) * NC_HALO + px + t % 3) * NC_LDW + 4 * l16);
 #pragma unroll
-                for (int n = 0; n < N; ++n)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[n][t][j] += g[n] * x[j];
+                for (int j = 0; j < 4; ++j) lds[pg * NC_CB + 4 * l16 + j] = acc[n][t][j];
+                __syncthreads();
+                if (threadIdx.x < NC_CB) {
+                    float v = 0.f;
+                    for (int q = 0; q < 16; ++q) v += lds[q * NC_CB + threadIdx.x];
+                    a.out[(int64_t)col0 * NC_CB * 9 + (n * NC_CB + threadIdx.x) * 9 + t] = v;
+                }
+                __syncthreads();
             }
-        }
-        __syncthreads();
+        return;
     }
     // combine the 16 pixel groups in LDS ([n][c][t], the output layout), then one global atomic per element
     for (int i = threadIdx.x; i < N * NC_CB * 9; i += 256) red[i] = 0.f;
@@ -249,16 +273,16 @@ __device__ __forceinline__ void nconv_wgrad_body(const NconvArgs &a, float *lds,
     }
 }
 
-template <int NMAX>
+template <int NMAX, bool ORDERED>
 __global__ __launch_bounds__(256) void k_nconv_wgrad(const NconvArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[NC_HALO * NC_HALO * NC_LDW];
     __shared__ float g_l[NC_T * NC_T * NC_MAXN];
     __shared__ float red[NC_MAXN * NC_CB * 9];
     const int n = a.n_out[blockIdx.y];
-    if (n == 1) nconv_wgrad_body<1>(a, lds, g_l, red);
-    else if (n == 2) nconv_wgrad_body<2>(a, lds, g_l, red);
-    else if (n == 3 || NMAX == 3) nconv_wgrad_body<3>(a, lds, g_l, red);
-    else nconv_wgrad_body<NMAX>(a, lds, g_l, red);
+    if (n == 1) nconv_wgrad_body<1, ORDERED>(a, lds, g_l, red);
+    else if (n == 2) nconv_wgrad_body<2, ORDERED>(a, lds, g_l, red);
+    else if (n == 3 || NMAX == 3) nconv_wgrad_body<3, ORDERED>(a, lds, g_l, red);
+    else nconv_wgrad_body<NMAX, ORDERED>(a, lds, g_l, red);
 }
 
 static int fill_args(NconvArgs &a, const char *who, int B, int H, int W, int ldy, int NO, int NB, const int32_t *cin_off, const int32_t *col_off,
@@ -315,8 +339,14 @@ extern "C" int rd_nconv_wgrad(const float *y, int ldy, const float *grad_out, in
     int rc = fill_args(a, "rd_nconv_wgrad", B, H, W, ldy, NO, NB, cin_off, col_off, n_out);
     if (rc) return rc;
     a.y = y; a.go = grad_out; a.out = grad_w;
+    if (g_deterministic) {
+        dim3 grid1(1, (unsigned)NB);
+        if (max_width(a) <= 3) k_nconv_wgrad<3, true><<<grid1, 256, 0, S(stream)>>>(a);
+        else k_nconv_wgrad<4, true><<<grid1, 256, 0, S(stream)>>>(a);
+        return check_launch("rd_nconv_wgrad");
+    }
     dim3 grid((unsigned)(B * cdiv(H, NC_T)), (unsigned)NB);
-    if (max_width(a) <= 3) k_nconv_wgrad<3><<<grid, 256, 0, S(stream)>>>(a);
-    else k_nconv_wgrad<4><<<grid, 256, 0, S(stream)>>>(a);
+    if (max_width(a) <= 3) k_nconv_wgrad<3, false><<<grid, 256, 0, S(stream)>>>(a);
+    else k_nconv_wgrad<4, false><<<grid, 256, 0, S(stream)>>>(a);
     return check_launch("rd_nconv_wgrad");
 }

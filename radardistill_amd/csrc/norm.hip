@@ -67,6 +67,7 @@ static int colreduce(int64_t rows, int C, F f, float *out1, float *out2, hipStre
     const int chunks = (int)cdiv(C, RED_CHUNK);
     static const int red_max = getenv("RD_RED_MAX_BLOCKS") ? atoi(getenv("RD_RED_MAX_BLOCKS")) : RED_MAX_BLOCKS;    // tuning knob
     int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(red_max, cdiv(rows, (int64_t)groups * 8)));
+    if (g_deterministic) blocks = 1;       // one contributor per output element: fixed summation order
     size_t shm = (size_t)groups * 2 * cw * 4;
     k_colreduce<F><<<dim3(blocks, chunks), 256, shm, st>>>(rows, C, f, out1, out2);
     return check_launch(who);

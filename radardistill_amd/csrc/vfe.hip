@@ -36,10 +36,25 @@ __global__ void k_pillar_acc(const float *__restrict__ points, int n, int stride
     atomicAdd(&acc[r * 4 + 3], 1.0f);
 }
 
+// rd_set_deterministic(1): thread t owns the pillars with row % 256 == t and adds their points in point order (no atomics).
+__global__ __launch_bounds__(256) void k_pillar_acc_ordered(const float *__restrict__ points, int n, int stride, const int32_t *__restrict__ point_row,
+                                                            float *acc) {
+    for (int i = 0; i < n; ++i) {
+        const int r = point_row[i];
+        if (r < 0 || (r & 255) != (int)threadIdx.x) continue;
+        const float *p = points + (int64_t)i * stride;
+        acc[r * 4 + 0] += p[1];
+        acc[r * 4 + 1] += p[2];
+        acc[r * 4 + 2] += p[3];
+        acc[r * 4 + 3] += 1.0f;
+    }
+}
+
 extern "C" int rd_vfe_pillar_mean(const float *points, int n_points, int n_feat, const int32_t *point_row, int n_pillars, float *pillar_acc, void *stream) {
     hipStream_t st = S(stream);
     if (n_pillars > 0) RD_HIP(hipMemsetAsync(pillar_acc, 0, (size_t)n_pillars * 16, st));
-    if (n_points > 0) k_pillar_acc<<<cdiv(n_points, 256), 256, 0, st>>>(points, n_points, 1 + n_feat, point_row, pillar_acc);
+    if (n_points > 0 && g_deterministic) k_pillar_acc_ordered<<<1, 256, 0, st>>>(points, n_points, 1 + n_feat, point_row, pillar_acc);
+    else if (n_points > 0) k_pillar_acc<<<cdiv(n_points, 256), 256, 0, st>>>(points, n_points, 1 + n_feat, point_row, pillar_acc);
     return check_launch("rd_vfe_pillar_mean");
 }
 
@@ -125,7 +140,7 @@ extern "C" int rd_vfe_linear_stats(const float *points, int n_points, int n_feat
     hipStream_t st = S(stream);
     RD_HIP(hipMemsetAsync(stats, 0, 65 * 4, st));
     if (n_points > 0) {
-        int blocks = (int)std::min<int64_t>(cdiv(n_points, 8), 1024);
+        int blocks = g_deterministic ? 1 : (int)std::min<int64_t>(cdiv(n_points, 8), 1024);
         VFE_DISPATCH(n_feat, k_vfe_stats<NFC><<<blocks, 256, 0, st>>>(points, n_points, point_row, coords, pillar_acc, weight, geom, stats));
     }
     return check_launch("rd_vfe_linear_stats");
@@ -291,10 +306,10 @@ extern "C" int rd_vfe_backward(const float *points, int n_points, int n_feat, co
     RD_HIP(hipMemsetAsync(dz, 0, (size_t)n_points * VFE_OUT * 4, st));
     int64_t n_pc = (int64_t)n_pillars * VFE_OUT;
     k_vfe_bwd_scatter<<<cdiv(n_pc, 256), 256, 0, st>>>(grad_out, argmax, nullptr, n_pc, dz);
-    int blocks = (int)std::min<int64_t>(cdiv(n_points, 8), 1024);
+    int blocks = g_deterministic ? 1 : (int)std::min<int64_t>(cdiv(n_points, 8), 1024);
     VFE_DISPATCH(n_feat, k_vfe_bwd_reduce<NFC><<<blocks, 256, 0, st>>>(points, n_points, point_row, coords, pillar_acc, weight, geom, mean, rstd,
                                                                        gamma, beta, dz, grad_gamma, grad_beta));
-    int blocks2 = (int)std::min<int64_t>(cdiv(n_points, 8), 256);
+    int blocks2 = g_deterministic ? 1 : (int)std::min<int64_t>(cdiv(n_points, 8), 256);
     VFE_DISPATCH(n_feat, k_vfe_bwd_weight<NFC><<<blocks2, 256, 0, st>>>(points, n_points, point_row, coords, pillar_acc, weight, geom, mean, rstd,
                                                                         gamma, dz, grad_gamma, grad_beta, 1.0f / (float)n_valid, grad_weight));
     return check_launch("rd_vfe_backward");

@@ -780,6 +780,17 @@ def boxes_overlap_bev(boxes_a, boxes_b):
     return out
 
 
+# ------------------------------------------------------------------------------------------ test switch: ordered reductions
+def set_deterministic(on):
+    """rd_set_deterministic: every floating-point reduction of the library in one fixed order (slow; for tests that must tell a
+    scheduling defect from summation-order noise)."""
+    check(native.lib().rd_set_deterministic(int(bool(on))), "rd_set_deterministic")
+
+
+def get_deterministic():
+    return bool(native.lib().rd_get_deterministic())
+
+
 # ------------------------------------------------------------------------------------------ arithmetic mode of the conv kernels
 _CONV_MATH = ["f32"]
 

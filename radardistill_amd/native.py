@@ -51,6 +51,8 @@ SIGNATURES = {
     "rd_last_error": (ctypes.c_char_p, []),
     "rd_abi_version": (c_int, []),
     "rd_device_ok": (c_int, []),
+    "rd_set_deterministic": (c_int, [c_int]),
+    "rd_get_deterministic": (c_int, []),
     "rd_rankgrid_bytes": (c_i64, [c_i64]),
     "rd_voxelize": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_f32, c_f32, c_f32, c_f32, _P, _P, _P]),
     "rd_rankgrid_coords": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P]),

@@ -336,53 +336,113 @@ def _build_pillarnet(grid):
     return m, c, pc_range, voxel, gs
 
 
-def test_full_distillation_step_vs_oracle(grad_tol=1e-1, tensor_tol=2e-1):
-    """Config C4 at reduced size (128 x 128 BEV, B = 2): loss, every tb entry and the gradients of a training step."""
+def _oracle_step(model, batch, pc_range, voxel, gs, B, dtype):
+    """The CPU oracle's training step in `dtype` on the model's current weights -> (loss, tb, {name: gradient})."""
+    state = {k: (v.detach().cpu().clone().to(dtype) if v.is_floating_point() else v.detach().cpu().clone()) for k, v in model.state_dict().items()}
+    trainable = [k for k, p in model.named_parameters() if p.requires_grad]
+    for k in trainable:
+        state[k].requires_grad_(True)
+    ob = {"points": torch.from_numpy(batch["points"]).to(dtype), "radar_points": torch.from_numpy(batch["radar_points"]).to(dtype),
+          "gt_boxes": torch.from_numpy(batch["gt_boxes"]).to(dtype), "batch_size": B}
+    oloss, otb, _ = opn.forward_train(state, ob, pc_range, voxel, gs)
+    oloss = oloss.mean()
+    oloss.backward()
+    return oloss.detach(), otb, {k: (state[k].grad if state[k].grad is not None else torch.zeros_like(state[k])) for k in trainable}
+
+
+def test_full_distillation_step_vs_oracle(noise_factor=2.5, whole_factor=2.0, tensor_tol=1e-3):
+    """Config C4 at reduced size (128 x 128 BEV, B = 2): loss, every tb entry and all ~500 gradients of a training step, with the
+    library's reductions in fixed order (rd_set_deterministic) so that the HIP side is one reproducible answer.
+
+    Gradient bound.  Two fp32 evaluations of this network disagree on the SIGN of a handful of ~1e-8 ReLU inputs, and each flip
+    moves a few gradient rows by O(1): the fp32 CPU oracle itself sits ~1e-2 (relative L2, per tensor) from the fp64 oracle, so
+    no fp32 implementation -- the reference's included -- can be held to 1e-3 against it.  The check is therefore made against
+    the EXACT gradient (the oracle in fp64): a tensor passes at `tensor_tol` (1e-3), or when HIP is at most `noise_factor` times as
+    far from the fp64 gradient as the fp32 oracle is; the whole gradient likewise with `whole_factor`.  A scheduling or indexing defect moves
+    tensors by 10 %+ (the one race found in round 1: 300-600 %), an order of magnitude outside this bound."""
+    from radardistill_amd import kernels as K
     from radardistill_amd.pcdet.models import model_fn_decorator
     grid, B = 128, 2
     model, cfg, pc_range, voxel, gs = _build_pillarnet(grid)
     sd = model.state_dict(); seeded_fill_(sd, seed=77); model.load_state_dict(sd)
-    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    trainable = [k for k, p in model.named_parameters() if p.requires_grad]
-    for k in trainable:
-        state[k].requires_grad_(True)
-    model = model.to(DEV)
     batch = make_batch(batch_size=B, n_lidar=300, n_radar=700, n_boxes=10, grid=grid, seed=5)   # sparse lidar: AFD is NaN by definition when every 8x cell is lidar-active
+    o32 = _oracle_step(model, batch, pc_range, voxel, gs, B, torch.float32)
+    o64 = _oracle_step(model, batch, pc_range, voxel, gs, B, torch.float64)
+    model = model.to(DEV)
     model.train()
-    loss, tb, _ = model_fn_decorator()(model, {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in batch.items()})
-    loss.backward()
-    ob = {"points": torch.from_numpy(batch["points"]), "radar_points": torch.from_numpy(batch["radar_points"]),
-          "gt_boxes": torch.from_numpy(batch["gt_boxes"]), "batch_size": B}
-    oloss, otb, inter = opn.forward_train(state, ob, pc_range, voxel, gs)
-    oloss = oloss.mean()
-    oloss.backward()
-    print("loss hip/oracle", float(loss), float(oloss))
-    close(loss, oloss, rtol=1e-3, atol=1e-5, what="total loss")
-    for k, v in otb.items():
+    K.set_deterministic(True)
+    try:
+        loss, tb, _ = model_fn_decorator()(model, {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in batch.items()})
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        K.set_deterministic(False)
+    print("loss hip / oracle fp32 / oracle fp64", float(loss), float(o32[0]), float(o64[0]))
+    close(loss, o32[0], rtol=1e-3, atol=1e-5, what="total loss")
+    close(loss, o64[0].float(), rtol=1e-3, atol=1e-5, what="total loss vs fp64")
+    for k, v in o32[1].items():
         close(tb[k], v, rtol=2e-3, atol=1e-5, what=k)
     named = dict(model.named_parameters())
-    worst = ("", 0.0)
-    gscale = max(float(state[k].grad.abs().max()) for k in trainable if state[k].grad is not None)
-    tot_err2 = tot_ref2 = 0.0
-    for k in trainable:
-        a, b = named[k].grad, state[k].grad
+    g32, g64 = o32[2], o64[2]
+    gscale = max(float(g.abs().max()) for g in g64.values())
+    worst, at_1e3 = ("", 0.0), 0
+    e_hip2 = e_o322 = ref2 = 0.0
+    for k, ref in g64.items():
+        a = named[k].grad
         assert a is not None, k
-        if b is None:
-            b = torch.zeros_like(state[k])
-        # Relative L2 per tensor.  fp32 HIP and fp32 torch-CPU disagree on the SIGN of ~1e-8 pre-activations, which flips the ReLU
-        # mask of those elements and moves individual tensors by a few percent from run to run (BatchNorm statistics and weight
-        # gradients are accumulated with atomics); tools/diag/grad_noise.py shows the fp32 oracle is as far from the fp64 oracle.
-        # Every op is held to 1e-3 in its own test; here a loose per-tensor bound plus a tight bound on the whole gradient.
-        err = float((a.detach().cpu() - b).norm())
-        tot_err2 += err * err
-        tot_ref2 += float(b.norm()) ** 2
-        bound = tensor_tol * float(b.norm()) + 1e-4 * gscale * (b.numel() ** 0.5)
-        if err / bound > worst[1]:
-            worst = (k, err / bound)
-        assert err <= bound, (k, err, float(b.norm()), gscale)
-    print("worst gradient error / bound", worst, "whole-gradient relative L2", (tot_err2 / tot_ref2) ** 0.5)
-    assert (tot_err2 / tot_ref2) ** 0.5 <= grad_tol, (tot_err2 ** 0.5, tot_ref2 ** 0.5)
+        e_hip = float((a.detach().cpu().double() - ref).norm())
+        e_o32 = float((g32[k].double() - ref).norm())
+        rn = float(ref.norm())
+        e_hip2 += e_hip ** 2; e_o322 += e_o32 ** 2; ref2 += rn ** 2
+        floor = 1e-5 * gscale * (ref.numel() ** 0.5)          # conv biases in front of a BatchNorm: the exact gradient is 0
+        bound = max(tensor_tol * rn, noise_factor * e_o32) + floor
+        at_1e3 += e_hip <= 1e-3 * rn + floor
+        if e_hip / bound > worst[1]:
+            worst = (k, e_hip / bound)
+        assert e_hip <= bound, (k, "hip vs fp64", e_hip / (rn + 1e-30), "fp32 oracle vs fp64", e_o32 / (rn + 1e-30))
+    whole_hip, whole_o32 = (e_hip2 / ref2) ** 0.5, (e_o322 / ref2) ** 0.5
+    print(f"{at_1e3} of {len(g64)} tensors within 1e-3 of the fp64 gradient; worst error / bound {worst}; whole-gradient relative L2: "
+          f"hip {whole_hip:.3e}, fp32 oracle {whole_o32:.3e}")
+    assert whole_hip <= max(1e-3, whole_factor * whole_o32), (whole_hip, whole_o32)
     assert int(model.global_step) == 1
+
+
+def test_deterministic_mode_is_bit_reproducible():
+    """rd_set_deterministic(1): the same step twice gives bit-identical loss terms and gradients (with the default atomics they differ
+    in the last bits and, through ReLU sign flips, by percents on some tensors)."""
+    from radardistill_amd import kernels as K
+    from radardistill_amd.pcdet.models import model_fn_decorator
+    grid, B = 128, 2
+    model, cfg, pc_range, voxel, gs = _build_pillarnet(grid)
+    sd = model.state_dict(); seeded_fill_(sd, seed=77); model.load_state_dict(sd)
+    state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    batch = make_batch(batch_size=B, n_lidar=2500, n_radar=700, n_boxes=10, grid=grid, seed=5)
+    fn = model_fn_decorator()
+
+    def run():
+        model.load_state_dict(state0)
+        model.train()
+        model.zero_grad(set_to_none=True)
+        loss, tb, _ = fn(model, {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in batch.items()})
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), {k: v.detach().clone() if torch.is_tensor(v) else v for k, v in tb.items()}, \
+            {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    assert not K.get_deterministic()
+    K.set_deterministic(True)
+    try:
+        assert K.get_deterministic()
+        (l1, t1, g1), (l2, t2, g2) = run(), run()
+    finally:
+        K.set_deterministic(False)
+    assert torch.equal(l1, l2)
+    for k in t1:
+        assert (torch.equal(torch.as_tensor(t1[k]), torch.as_tensor(t2[k])) or (np.isnan(float(t1[k])) and np.isnan(float(t2[k])))), k
+    assert g1.keys() == g2.keys()
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
 
 
 @pytest.mark.parametrize("grid,B,n_boxes", [(512, 8, 30), (128, 3, 120)])
@@ -428,17 +488,20 @@ def test_bf16x3_conv_math_parity(golden_dir):
         test_radar_distill_forward_golden(golden_dir)
         test_center_head_golden(golden_dir)
         # losses / tb entries keep the 1e-3..2e-3 bounds; the whole-network gradient comparison sees more ReLU sign flips at 4e-6
-        # forward noise than at 4e-7, hence the wider L2 bound (every op above was just held to 1e-3)
-        test_full_distillation_step_vs_oracle(grad_tol=1.5e-1, tensor_tol=3e-1)
+        # forward noise than at 4e-7, hence the wider multiples of the fp32 oracle's own distance from the fp64 gradient
+        # (bf16x3 products carry 4e-6 instead of 4e-7: ~10x the pre-activations change sign, also in tensors where the fp32 oracle
+        # happens to have no flip at all, hence a per-tensor floor of 5e-2; the whole gradient stays within 4x the fp32 oracle's distance: measured 2.8x)
+        test_full_distillation_step_vs_oracle(noise_factor=8.0, whole_factor=4.0, tensor_tol=5e-2)
     finally:
         K.set_conv_math("f32")
 
 
 def test_teacher_prefetch_gives_the_same_step():
     """PillarNet.prefetch_teacher (teacher branch of the NEXT batch enqueued between backward and optimizer.step) against the plain
-    forward on the same batches: identical loss values and gradients up to atomics noise, over three pipelined steps with two
-    alternating batches; a dict that was not prefetched still takes the plain path."""
+    forward on the same batches: BIT-IDENTICAL loss values and gradients (reductions in fixed order, rd_set_deterministic), over three
+    pipelined steps with two alternating batches; a dict that was not prefetched still takes the plain path."""
     import os
+    from radardistill_amd import kernels as K
     from radardistill_amd.pcdet.models import model_fn_decorator
     grid, B = 128, 2
     model, cfg, pc_range, voxel, gs = _build_pillarnet(grid)
@@ -468,20 +531,20 @@ def test_teacher_prefetch_gives_the_same_step():
             out.append((float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}))
         return out
 
+    K.set_deterministic(True)
     try:
         ref, got = run(False), run(True)
     finally:
+        K.set_deterministic(False)
         if prev is None:
             os.environ.pop("RD_TEACHER_PREFETCH", None)
         else:
             os.environ["RD_TEACHER_PREFETCH"] = prev
     for (lr, gr), (lg, gg) in zip(ref, got):
-        assert abs(lr - lg) <= 1e-4 * abs(lr), (lr, lg)
-        top = max(float(v.norm()) for v in gr.values())
+        assert lr == lg, (lr, lg)
+        assert gr.keys() == gg.keys()
         for k, r in gr.items():
-            rn = float(r.norm())
-            if rn >= 1e-4 * top:
-                assert float((gg[k] - r).norm()) / rn < 0.3, k
+            assert torch.equal(gg[k], r), k
 
 
 def test_operand_cache_multi_refresh_matches_single_conversions():
@@ -520,11 +583,12 @@ def test_operand_cache_multi_refresh_matches_single_conversions():
 
 def test_stream_overlaps_do_not_change_gradients():
     """The same training step with every stream feature off (geometry prelude, weight-gradient side stream, teacher stream) and with
-    all of them on, once as a single backward pass and once accumulating two passes into .grad: every parameter gradient agrees up
-    to atomics / ReLU-flip noise.  (Regression: a strided dwconv weight gradient produced on the side stream was cloned by
-    AccumulateGrad on the main stream before it was written: 300-600 % error on that tensor only.)"""
+    all of them on, once as a single backward pass and once accumulating two passes into .grad: with the library's reductions in
+    fixed order (rd_set_deterministic) every parameter gradient is BIT-IDENTICAL -- stream placement may change when a kernel runs,
+    never what it computes, so any missing wait_event / record_stream shows as a plain inequality.  (Regression: a strided dwconv
+    weight gradient produced on the side stream was cloned by AccumulateGrad on the main stream before it was written.)"""
     import os
-    from radardistill_amd import autograd as A
+    from radardistill_amd import autograd as A, kernels as K
     from radardistill_amd.pcdet.models import model_fn_decorator
     grid, B = 128, 2
     model, cfg, pc_range, voxel, gs = _build_pillarnet(grid)
@@ -546,17 +610,15 @@ def test_stream_overlaps_do_not_change_gradients():
         torch.cuda.synchronize()
         return {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
 
+    K.set_deterministic(True)
     try:
         for passes in (1, 2):
             ref, got = grads(False, passes), grads(True, passes)
-            top = max(float(v.norm()) for v in ref.values())
+            assert ref.keys() == got.keys()
             for k, r in ref.items():
-                rn = float(r.norm())
-                if rn < 1e-4 * top:              # conv biases in front of a BatchNorm: the true gradient is 0, what is left is rounding noise
-                    continue
-                rel = float((got[k] - r).norm()) / rn
-                assert rel < 0.3, (passes, k, rel)
+                assert torch.equal(got[k], r), (passes, k, float((got[k] - r).norm()) / (float(r.norm()) + 1e-30))
     finally:
+        K.set_deterministic(False)
         A.WGRAD_STREAM[0] = wg0
         for k, v in saved.items():
             if v is None:
@@ -909,3 +971,34 @@ def test_training_step_at_the_reference_yaml_geometry():
         perm[key] = np.concatenate(parts, 0)
     loss_c, tb_c, _ = run(perm)
     assert abs(loss_a - loss_c) <= 2e-4 * abs(loss_a), (loss_a, loss_c)
+
+
+def test_afd_nan_edge_gradient_contract():
+    """The documented deviation in the AFD edge case.  When no (radar-active, LiDAR-inactive) cell exists the reference's
+    `mask_ir * (N_ar / N_ir)` is 0 * inf: the forward value is NaN (reproduced, fixture g3) and torch autograd then writes NaN into
+    the WHOLE radar-map gradient, which ends the reference run at the next optimizer step.  rd_afd_bwd instead returns the gradient
+    of the terms that are defined -- the active-region MSE and the mask L1 -- with nothing from the empty region: finite everywhere,
+    equal to autograd on those terms.  (Reachable: ~360 steps of overfitting two synthetic batches, tools/diag/nan_hunt.py.)"""
+    m = _radar_distill()
+    r = np.random.default_rng(41)
+    lid = torch.from_numpy(np.abs(r.normal(0.2, 1, size=(2, 256, 16, 16))).astype(np.float32) + 1.0)      # every cell LiDAR-active
+    rad = torch.from_numpy(r.normal(0.0, 1, size=(2, 256, 16, 16)).astype(np.float32))
+    rd = _cl(rad).requires_grad_(True)
+    f, ml = m.low_loss(_cl(lid), rd)
+    assert torch.isnan(f).item() and torch.isfinite(ml).item()
+    (f * 2.5 + ml * 2.5).backward()                       # the weights get_loss applies: 5 * 0.5
+    assert bool(torch.isfinite(rd.grad).all())
+    # the reference expression, term by term: its gradient is NaN everywhere ...
+    ro = rad.clone().requires_grad_(True)
+    fo, mo = obev.low_loss(lid, ro)
+    assert torch.isnan(fo).item()
+    (fo * 2.5 + mo * 2.5).backward()
+    assert bool(torch.isnan(ro.grad).all())
+    # ... and the defined terms alone give what the kernel returns
+    rr = rad.clone().requires_grad_(True)
+    lidar_mask = (lid.sum(1, keepdim=True) > 0).float()
+    radar_sum = rr.sum(1, keepdim=True)
+    m_ar = (((radar_sum > 0).float() + 0.5 * lidar_mask) == 1.5).float()
+    defined = 3e-4 * (F.mse_loss(rr, lid, reduction="none") * m_ar).sum() / 2 * 2.5 + F.l1_loss(torch.sigmoid(radar_sum), lidar_mask) * 2.5
+    defined.backward()
+    close(rd.grad, rr.grad, rtol=1e-3, atol=1e-6 * float(rr.grad.abs().max()), what="AFD gradient in the NaN edge")
