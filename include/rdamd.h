@@ -417,6 +417,27 @@ int rd_center_loss_fwd(const rd_center_loss_cfg *cfg, const float *maps, const f
 int rd_center_loss_bwd(const rd_center_loss_cfg *cfg, const float *maps, const float *heatmaps, const int64_t *inds, const int64_t *masks,
                        const float *scale, const float *ws, const float *grad_loss, float *grad_maps, void *stream);
 
+/* ---- Q. Low-precision DenseEnc path (BASELINE configs[2] bf16 and configs[4] fp8): the frozen teacher's dense BEV convolutions
+ * (BaseBEVBackboneV2, pcdet/models/backbones_2d/base_bev_backbone.py:206-308, eval mode: every layer is conv -> folded BatchNorm
+ * -> ReLU) with activations and weights STORED as bf16 (dtype 0) or OCP fp8 e4m3fn (dtype 1) and accumulated in fp32 on the
+ * matrix cores (v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x64_f8f6f4).  Replaces cuDNN's fp32 / TF32 conv2d + ATen
+ * batch_norm + relu for those modules.  All maps are channels-last rows (B*H*W, ld) of the narrow type.
+ *   rd_lp_cast          x (rows, C) fp32 -> narrow, value * mul, written at column out_col0 of rows of pitch out_ld (concat by placement)
+ *   rd_lp_uncast        n narrow elements -> fp32, value * mul
+ *   rd_lp_amax          out1[0] = max |x| (calibration of the per-tensor activation scale)
+ *   rd_lp_quant_weights w_k (Cout, K = taps * Cin) fp32 kernel layout -> narrow; fp8: per-output-channel scale w_scale[co] =
+ *                       max|w[co]| / 448 and w_q = w / w_scale; bf16: w_scale = 1
+ *   rd_lp_conv          ksize 3 (pad 1, stride 1), 1, or deconv = 1 with ksize 2 (ConvTranspose2d k2 s2: output map (2H, 2W),
+ *                       weights [Cout][dy*2+dx][Cin]): out[p][out_col0 + co] = act(acc * alpha[co] + beta[co]), out_dtype 0 bf16,
+ *                       1 fp8, 2 fp32.  alpha folds the input scale, the weight scale, the BatchNorm scale and 1 / output scale;
+ *                       beta the BatchNorm shift / output scale.  Cin must be a multiple of 32 (bf16) / 64 (fp8). */
+int rd_lp_cast(const float *x, int64_t rows, int C, int dtype, float mul, void *out, int out_ld, int out_col0, void *stream);
+int rd_lp_uncast(const void *x, int64_t n, int dtype, float mul, float *out, void *stream);
+int rd_lp_amax(const float *x, int64_t n, float *out1, void *stream);
+int rd_lp_quant_weights(const float *w_k, int Cout, int K, int dtype, void *w_q, float *w_scale, void *stream);
+int rd_lp_conv(const void *in, int dtype, int B, int H, int W, int Cin, int in_ld, const void *w_q, int ksize, int deconv, const float *alpha,
+               const float *beta, int relu, void *out, int out_dtype, int Cout, int out_ld, int out_col0, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
