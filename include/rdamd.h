@@ -251,6 +251,9 @@ int64_t rd_afd_ws_bytes(int64_t rows);
 int rd_afd_fwd(const float *lidar, const float *radar_a, const float *radar_b, int64_t rows, int C, int batch, float *out, float *coef,
                float *rowinfo, float *ws, int64_t ws_bytes, void *stream);
 /* gscale[4] (device) = upstream gradients of out[4]. */
+/* rd_afd_fwd on maps stored as bf16 (section Q, BASELINE configs[2]); same outputs, sums in fp32. */
+int rd_afd_fwd_bf16(const void *lidar, const void *radar_a, const void *radar_b, int64_t rows, int C, int batch, float *out, float *coef,
+                    float *rowinfo, float *ws, int64_t ws_bytes, void *stream);
 int rd_afd_bwd(const float *lidar, const float *radar_a, const float *radar_b, int64_t rows, int C, const float *rowinfo, const float *coef,
                const float *gscale, float *grad_a, float *grad_b, void *stream);
 /* PFD: gt_hm / hm_logits (rows, n_hm) concatenated heat-map channels; cls[rows] int8, counts[2] int32 saved for backward;

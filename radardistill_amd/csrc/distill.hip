@@ -29,7 +29,19 @@ __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x))
 // partial layout per block: [2 maps][5] = S_ar, S_ir, N_ar, N_ir, M.  rowinfo[2][rows] keeps (class, rs) for the backward.
 constexpr int AFD_Q = 5;
 
-__global__ __launch_bounds__(256) void k_afd_fwd(const float *__restrict__ lidar, const float *__restrict__ ra, const float *__restrict__ rb,
+// T = float, or __bf16 for maps stored in bf16 (BASELINE configs[2]: half the bytes of this HBM-bound pass; sums stay fp32)
+template <typename T>
+__device__ __forceinline__ f32x4 load4(const T *p);
+template <>
+__device__ __forceinline__ f32x4 load4<float>(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+template <>
+__device__ __forceinline__ f32x4 load4<__bf16>(const __bf16 *p) {
+    const uint2 u = *reinterpret_cast<const uint2 *>(p);
+    return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_afd_fwd(const T *__restrict__ lidar, const T *__restrict__ ra, const T *__restrict__ rb,
                                                  int64_t rows, int C, float *partial, float *rowinfo) {
     __shared__ float red[4][2 * AFD_Q];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -39,9 +51,9 @@ __global__ __launch_bounds__(256) void k_afd_fwd(const float *__restrict__ lidar
     for (int64_t r = (int64_t)blockIdx.x * 4 + wid; r < rows; r += (int64_t)gridDim.x * 4) {
         float ls = 0.f, s[2] = {0.f, 0.f}, mse[2] = {0.f, 0.f};
         for (int c = lane * 4; c < C; c += 256) {
-            const f32x4 l = *reinterpret_cast<const f32x4 *>(lidar + r * C + c);
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(ra + r * C + c);
-            const f32x4 b = *reinterpret_cast<const f32x4 *>(rb + r * C + c);
+            const f32x4 l = load4<T>(lidar + r * C + c);
+            const f32x4 a = load4<T>(ra + r * C + c);
+            const f32x4 b = load4<T>(rb + r * C + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 ls += l[e];
@@ -120,9 +132,22 @@ extern "C" int rd_afd_fwd(const float *lidar, const float *radar_a, const float 
     RD_REQUIRE(ws_bytes >= 1024 * 2 * AFD_Q * 4, "rd_afd_fwd: workspace too small");
     hipStream_t st = S(stream);
     int blocks = (int)std::min<int64_t>(1024, cdiv(rows, 4));
-    k_afd_fwd<<<blocks, 256, 0, st>>>(lidar, radar_a, radar_b, rows, C, ws, rowinfo);
+    k_afd_fwd<float><<<blocks, 256, 0, st>>>(lidar, radar_a, radar_b, rows, C, ws, rowinfo);
     k_afd_final<<<1, 64, 0, st>>>(ws, blocks, 1.0f / batch, 1.0f / (float)rows, out, coef);
     return check_launch("rd_afd_fwd");
+}
+
+// Same forward on maps STORED in bf16 (rd_lp_cast dtype 0 / the bf16 outputs of rd_lp_conv): BASELINE configs[2].
+extern "C" int rd_afd_fwd_bf16(const void *lidar, const void *radar_a, const void *radar_b, int64_t rows, int C, int batch, float *out /*[4]*/,
+                               float *coef /*[6]*/, float *rowinfo /*[2][rows][2]*/, float *ws, int64_t ws_bytes, void *stream) {
+    RD_REQUIRE(C % 4 == 0 && rows > 0 && batch > 0, "rd_afd_fwd_bf16: bad sizes");
+    RD_REQUIRE(ws_bytes >= 1024 * 2 * AFD_Q * 4, "rd_afd_fwd_bf16: workspace too small");
+    hipStream_t st = S(stream);
+    int blocks = (int)std::min<int64_t>(1024, cdiv(rows, 4));
+    k_afd_fwd<__bf16><<<blocks, 256, 0, st>>>(reinterpret_cast<const __bf16 *>(lidar), reinterpret_cast<const __bf16 *>(radar_a),
+                                             reinterpret_cast<const __bf16 *>(radar_b), rows, C, ws, rowinfo);
+    k_afd_final<<<1, 64, 0, st>>>(ws, blocks, 1.0f / batch, 1.0f / (float)rows, out, coef);
+    return check_launch("rd_afd_fwd_bf16");
 }
 
 // grad_radar_m[r][c] = g_feat[m] * coef_cls * 2 (r - l) + g_mask[m] * inv_cells * sign(sigmoid(rs) - lm) * sigmoid'(rs)

@@ -537,6 +537,24 @@ def afd_fwd(lidar, radar_a, radar_b, batch):
     return out, coef, rowinfo
 
 
+def afd_fwd_bf16(lidar, radar_a, radar_b, batch):
+    """afd_fwd on maps stored in bf16 (BASELINE configs[2]) -> out[4] = (feature_a, mask_a, feature_b, mask_b)."""
+    for t in (lidar, radar_a, radar_b):
+        _chk(t, torch.bfloat16, "afd bf16 map", 2)
+    if not (lidar.shape == radar_a.shape == radar_b.shape):
+        raise RuntimeError("afd_fwd_bf16: map shapes differ")
+    rows, C = lidar.shape
+    dev = lidar.device
+    out = torch.empty(4, dtype=f32, device=dev)
+    coef = torch.empty(6, dtype=f32, device=dev)
+    rowinfo = torch.empty(2 * rows * 2, dtype=f32, device=dev)
+    nb = native.lib().rd_afd_ws_bytes(rows)
+    ws = torch.empty(nb // 4, dtype=f32, device=dev)
+    check(native.lib().rd_afd_fwd_bf16(_p(lidar), _p(radar_a), _p(radar_b), rows, C, batch, _p(out), _p(coef), _p(rowinfo), _p(ws), nb, _stream()),
+          "rd_afd_fwd_bf16")
+    return out
+
+
 def afd_bwd(lidar, radar_a, radar_b, rowinfo, coef, gscale):
     rows, C = lidar.shape
     ga, gb = torch.empty_like(radar_a), torch.empty_like(radar_b)

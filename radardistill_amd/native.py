@@ -92,6 +92,7 @@ SIGNATURES = {
     "rd_dcn_bwd_data": (c_int, [_P, c_int, _P, _P, c_int, _P, c_int, c_int] + [c_int] * 10 + [_P, _P, c_int, _P, c_int, _P]),
     "rd_afd_ws_bytes": (c_i64, [c_i64]),
     "rd_afd_fwd": (c_int, [_P, _P, _P, c_i64, c_int, c_int, _P, _P, _P, _P, c_i64, _P]),
+    "rd_afd_fwd_bf16": (c_int, [_P, _P, _P, c_i64, c_int, c_int, _P, _P, _P, _P, c_i64, _P]),
     "rd_afd_bwd": (c_int, [_P, _P, _P, c_i64, c_int, _P, _P, _P, _P, _P, _P]),
     "rd_pfd_fwd": (c_int, [_P, _P, _P, _P, c_i64, c_int, _P, _P, c_int, _P, _P, _P, _P, c_i64, _P]),
     "rd_pfd_bwd": (c_int, [_P, _P, _P, _P, c_i64, c_int, _P, _P, _P, _P, _P, _P]),

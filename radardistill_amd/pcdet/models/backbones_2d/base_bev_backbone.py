@@ -97,9 +97,34 @@ class BaseBEVBackboneV2(nn.Module):
         feat = run_block(self.blocks[0], torch.cat((x_conv4, up), dim=1))
         return up, feat
 
+    def _lowp_engine(self, x_conv4, x_conv5):
+        """MODEL.BACKBONE_2D.PRECISION: bf16 | fp8 (BASELINE configs[2] / [4]; default fp32): the FROZEN eval-mode DenseEnc on the
+        low-precision kernels (radardistill_amd/lowp.py).  Built once per weight version; fp8 scales are calibrated on the first
+        batch seen (a deployment would ship them with the checkpoint)."""
+        from radardistill_amd import lowp as LP
+        prec = str(self.model_cfg.get('PRECISION', 'fp32')).lower()
+        if prec in ('fp32', 'f32'):
+            return None
+        if prec not in ('bf16', 'fp8'):
+            raise ValueError(f"BACKBONE_2D.PRECISION: {prec!r} (fp32, bf16 or fp8)")
+        if self.training or any(p.requires_grad for p in self.parameters()) or not x_conv4.is_cuda:
+            raise RuntimeError("BACKBONE_2D.PRECISION bf16 / fp8 is an inference mode of the frozen teacher DenseEnc (eval mode, no gradients)")
+        ver = tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
+        eng = getattr(self, '_lowp', None)
+        if eng is None or eng[0] != (prec, ver):
+            e = LP.LowpDenseEnc(self, LP.BF16 if prec == 'bf16' else LP.FP8)
+            if prec == 'fp8':
+                e.calibrate(x_conv4, x_conv5)
+            eng = self._lowp = ((prec, ver), e)
+        return eng[1]
+
     def forward(self, data_dict):
         sf = data_dict['multi_scale_2d_features']
-        up, feat = self.dense_enc(sf['x_conv4'], sf['x_conv5'])
+        eng = self._lowp_engine(sf['x_conv4'], sf['x_conv5'])
+        if eng is not None:
+            up, feat = eng.forward(sf['x_conv4'], sf['x_conv5'])
+        else:
+            up, feat = self.dense_enc(sf['x_conv4'], sf['x_conv5'])
         data_dict['spatial_features_2d_8x'] = up
         data_dict['spatial_features_2d'] = feat
         return data_dict

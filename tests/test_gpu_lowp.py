@@ -146,3 +146,49 @@ def test_lowp_dense_enc_full_size_1024_bev(dtype, tol, B):
     flops = 2.0 * 9 * 256 * 256 * B * (128 * 128 * 5 + 64 * 64 * 6) + 2.0 * 9 * 512 * 256 * B * 128 * 128 + 2.0 * 4 * 256 * 256 * B * 64 * 64
     print(f"dtype {dtype} B {B}: rel L2 2d_8x {e_up:.3e} 2d {e_feat:.3e}; DenseEnc forward {ms:.3f} ms = {flops / ms / 1e9:.1f} TF/s algorithmic")
     assert e_up <= tol and e_feat <= tol
+
+
+def test_dual_branch_forward_and_afd_in_bf16():
+    """BASELINE configs[2] at full size (35k LiDAR + 2k radar points, 512 x 512 BEV, B = 8): both branches forward with the frozen
+    teacher's DenseEnc on bf16 storage (MODEL.BACKBONE_2D.PRECISION: bf16) and the AFD loss evaluated from bf16-stored maps
+    (rd_afd_fwd_bf16), against the same forward in the fp32 parity mode.  Stated tolerance: teacher maps 1e-2 relative L2 (8
+    mantissa bits through 13 layers, measured 3.5e-3), AFD feature / mask terms 1e-2 relative."""
+    from radardistill_amd import kernels as K
+    from radardistill_amd.pcdet.models import load_data_to_gpu
+    from radardistill_amd.synthetic import make_batch
+    from tests.test_gpu_model import _build_pillarnet
+    grid, B = 512, 8
+    model, cfg, pc_range, voxel, gs = _build_pillarnet(grid)
+    sd = model.state_dict(); seeded_fill_(sd, seed=77); model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    batch = make_batch(batch_size=B, n_lidar=35000, n_radar=2000, n_boxes=30, grid=grid, seed=3)
+
+    def forward(prec):
+        model.backbone_2d.model_cfg['PRECISION'] = prec
+        bd = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in batch.items()}
+        load_data_to_gpu(bd)
+        with torch.no_grad():
+            for m in model.module_list:
+                if m.__class__.__name__.endswith('CenterHead'):
+                    continue                                        # configs[2] stops at the feature maps + AFD
+                if hasattr(m, 'prepare'):
+                    m.prepare(bd)
+                bd = m(bd)
+        return bd
+
+    ref = forward('fp32')
+    got = forward('bf16')
+    for k in ('spatial_features_2d', 'spatial_features_2d_8x'):
+        e = _rel_l2(got[k], ref[k].cpu())
+        print(k, "bf16 vs fp32 relative L2", e)
+        assert e <= 1e-2, (k, e)
+    # AFD: fp32 kernel on fp32 maps vs the bf16-map kernel on bf16 copies of the same three maps
+    lid = ref['multi_scale_2d_features']['x_conv4']
+    ra = ref['radar_multi_scale_2d_features']['radar_spatial_features_8x_2']
+    rb = ref['radar_multi_scale_2d_features']['radar_spatial_features_8x_1']
+    rows = [t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous() for t in (lid, ra, rb)]
+    out32, _, _ = K.afd_fwd(rows[0], rows[1], rows[2], B)
+    out16 = K.afd_fwd_bf16(*[LP.lp_cast(r, LP.BF16) for r in rows], B)
+    print("AFD fp32", out32.tolist(), "bf16", out16.tolist())
+    assert bool(torch.isfinite(out32).all())
+    np.testing.assert_allclose(out16.cpu().numpy(), out32.cpu().numpy(), rtol=1e-2)
