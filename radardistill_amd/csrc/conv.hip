@@ -575,6 +575,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const WgradArgs a) {
     }
 }
 
+bool launch_wgrad_d3_b3(const float *in, int in_rows, int Cin, const float *go, int out_rows, int Cout, int taps, const rd_conv_index *ix, float *gw,
+                        hipStream_t st);
+
 static int conv_wgrad_impl(const float *in, int in_rows, int Cin, const float *grad_out, int out_rows, int Cout, int taps,
                            const rd_conv_index *idx, float *grad_wk, int in_split, int go_split, void *stream);
 
@@ -602,6 +605,9 @@ static int conv_wgrad_impl(const float *in, int in_rows, int Cin, const float *g
     // bf16x3 mode: every shape with Cout >= 64 and Cin >= 64 runs the split-bf16 kernel (Cin tile 128, or 64 when Cin == 64).
     // Exact fp32: 128-wide Cin tiles when that still leaves >= 32 (tap, tile) pairs to spread over the chip (3x3 convs); 1x1 keep 64.
     const bool b3 = g_conv_math == 1 && Cout >= 64 && Cin >= 64;
+    // dense stride-1 3x3 layers: the halo-staged kernel (conv_wgrad_d3.hip) runs all nine taps on one staged pixel tile
+    if (g_conv_math == 1 && !in_split && !go_split && launch_wgrad_d3_b3(in, in_rows, Cin, grad_out, out_rows, Cout, taps, idx, grad_wk, S(stream)))
+        return check_launch("rd_conv_wgrad(bf16x3, halo)");
     const bool wide = b3 ? Cin >= 128 : (Cin >= 128 && Cout >= 64 && (int64_t)taps * cdiv(Cout, WG_BM) * cdiv(Cin, 128) >= 32);
     const int bn = wide ? 128 : 64;
     const int n_mt = (int)cdiv(Cout, WG_BM), n_nt = (int)cdiv(Cin, bn);

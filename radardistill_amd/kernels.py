@@ -356,6 +356,10 @@ def conv_wgrad(x, grad_out, taps, ix, nbr_keepalive=None, in_split=False, go_spl
         b3 = get_conv_math() == "bf16x3" and Cout >= 64 and Cin >= 64
         wide = Cin >= 128 if b3 else (Cin >= 128 and Cout >= 64 and taps * ((Cout + 127) // 128) * ((Cin + 127) // 128) >= 32)
         tag = ("wgrad_b3_" if b3 else "wgrad_f32_") + ("deform_" if ix.mode == 3 else "") + ("128" if wide else "64")
+        if (get_conv_math() == "bf16x3" and ix.mode == 1 and taps == 9 and ix.KH == 3 and ix.KW == 3 and ix.stride == 1 and ix.pad == 1
+                and ix.Hin == ix.Hout and ix.Win == ix.Wout and not in_split and not go_split and Cin % 4 == 0 and Cout % 4 == 0 and Cin >= 32
+                and Cout >= 32 and in_rows == out_rows and os.environ.get("RD_WGRAD_D3", "1") != "0"):
+            tag = "wgrad_d3"
         WGRAD_PROFILE.append((e0, e1, pairs, 2.0 * Cin * Cout if pairs is not None else 2.0 * out_rows * taps * Cin * Cout,
                               (in_rows, Cin, Cout, taps, ix.mode, tag)))
     return gw

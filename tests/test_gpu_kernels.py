@@ -568,3 +568,42 @@ def test_full_size_voxelizer_and_rulebook_pyramid_bit_exact():
         assert np.array_equal(lvl.coords.cpu().numpy(), oidx) and np.array_equal(spec.fwd_nbr.cpu().numpy(), snbr), f"strided table, level {level}"
         t = SP.SparseConvTensor(torch.zeros((oidx.shape[0], 32), device=DEV), lvl.coords, [lvl.H, lvl.W], 8, _level=lvl)
         idx, (H, W) = oidx, oshape
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 21, 19, 64, 96),       # ragged map, one 64-channel ci tile, Cout not a tile multiple
+                                            (8, 64, 64, 256, 256),     # the DenseEnc shape of the bench (512 pixel tiles)
+                                            (1, 8, 8, 32, 64),         # a single tile, half-empty ci tile
+                                            (3, 16, 24, 512, 64),      # 8 ci tiles, half-empty co tile (CenterHead shared conv)
+                                            (2, 32, 32, 64, 448)])     # batched head branches: Cout not a multiple of 128
+def test_halo_wgrad_3x3_bf16x3(B, H, W, Cin, Cout):
+    """k_conv_wgrad_d3_b3 (conv_wgrad_d3.hip: dense stride-1 3x3 weight gradient, all nine taps on one staged tile, transposing LDS
+    reads) against torch's conv2d weight gradient in fp64 at the bf16x3 bound (1e-3 of max; observed ~1e-5), in the atomic
+    (chunked) and in the deterministic (one chunk) launch shape; the two must also agree with the gathered kernel it replaces."""
+    import os
+    from radardistill_amd import autograd as A, kernels as K
+    g = np.random.default_rng(B * 100 + H + Cin)
+    x = torch.from_numpy(g.normal(size=(B, Cin, H, W)).astype(np.float32))
+    go = torch.from_numpy(g.normal(size=(B, Cout, H, W)).astype(np.float32))
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(x.double(), w, None, 1, 1) * go.double()).sum().backward()
+    ref = w.grad.permute(0, 2, 3, 1).reshape(Cout, 9, Cin)                      # kernel layout [Cout][tap][Cin]
+    xr = x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().to(DEV)
+    gr = go.permute(0, 2, 3, 1).reshape(-1, Cout).contiguous().to(DEV)
+    spec = A.dense_conv_spec(B, H, W, 3, 3, 1, 1)
+    K.set_conv_math("bf16x3")
+    try:
+        A.begin_step(torch.device(DEV))
+        got = K.conv_wgrad(xr, gr, 9, spec.fwd_ix).clone()
+        K.set_deterministic(True)
+        det = K.conv_wgrad(xr, gr, 9, spec.fwd_ix).clone()
+        det2 = K.conv_wgrad(xr, gr, 9, spec.fwd_ix).clone()
+        K.set_deterministic(False)
+    finally:
+        K.set_deterministic(False)
+        K.set_conv_math("f32")
+    scale = float(ref.abs().max())
+    for name, t in (("chunked", got), ("one chunk", det)):
+        err = float((t.cpu().double() - ref).abs().max())
+        assert err <= 1e-3 * scale, (name, err, scale)
+    assert torch.equal(det, det2)
+    print("halo wgrad max err / max", float((got.cpu().double() - ref).abs().max()) / scale)
