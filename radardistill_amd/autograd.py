@@ -121,12 +121,26 @@ def end_forward():
         _BN_TOUCHED.clear()
 
 
+# HIP-graph capture of the dense section (radardistill_amd/graphs.py).  RULE: a captured launch may only touch memory that the
+# capture owns (allocated inside it, from the graph's private pool) or that is persistent for the life of the graph (parameters,
+# buffers, static inputs, the operand cache's buffers, constants created before the capture).  While CAPTURING is set, zero-filled
+# scratch therefore comes from torch.zeros (graph pool + a fill node that re-runs at every replay) instead of the per-step arenas
+# -- which are allocated and zeroed by begin_step() OUTSIDE any capture and re-zeroed only up to the eager high-water mark -- and
+# the version-keyed weight-layout cache is bypassed (its entries live in the eager pool and are replaced when weights change).
+# A plain module-level flag, not thread-local: the captured backward runs on the autograd engine's thread.
+CAPTURING = [False]
+
+
 def zeros_stats(n, device):
+    if CAPTURING[0]:
+        return torch.zeros(n, dtype=torch.float32, device=device)
     return ARENA.take(n, device)
 
 
 def zeros_accum(n, device):
     """Zero-filled accumulator whose result may be returned to autograd as a gradient."""
+    if CAPTURING[0]:
+        return torch.zeros(n, dtype=torch.float32, device=device)
     return GRAD_ARENA.take(n, device)
 
 
@@ -138,8 +152,8 @@ def kernel_weight(param, Cout, Cin, taps, kind, flip=False):
         src = src.contiguous()
     if kind == 0 and not flip:
         return src.reshape(Cout, taps, Cin)       # spconv layout [Cout,kh,kw,Cin] and nn.Linear [Cout,Cin] are already kernel layout
-    if not param.is_leaf:                         # a per-step tensor (e.g. the concatenated head-branch weights): nothing to cache on
-        return K.weight_layout(src, Cout, Cin, taps, kind, flip)
+    if not param.is_leaf or CAPTURING[0]:         # a per-step tensor (e.g. the concatenated head-branch weights): nothing to cache on;
+        return K.weight_layout(src, Cout, Cin, taps, kind, flip)      # under capture: converted by a node of the graph, every replay
     key = (id(param), kind, flip)
     ver = (param._version, _WEIGHTS_EPOCH[0] if param.requires_grad else -1, param.data_ptr())
     hit = _LAYOUT_CACHE.get(key)

@@ -182,7 +182,9 @@ class PillarRes18BackBone8x(nn.Module):
             lvl.subm_spec()
         batch_dict[p + '_sparse_input'] = x
 
-    def forward(self, batch_dict):
+    def forward_sparse(self, batch_dict):
+        """The data-dependent half: four sparse stages and `x_conv4.dense()` -> the (B, 256, H/8, W/8) map.  Everything after it
+        (conv5 and the 2-D modules) has static shapes; radardistill_amd/graphs.py replays that part as one HIP graph."""
         p = self.IN_PREFIX
         x = batch_dict.pop(p + '_sparse_input', None)
         if x is None:
@@ -191,8 +193,14 @@ class PillarRes18BackBone8x(nn.Module):
         x_conv1 = self.conv1(x)
         x_conv2 = self.conv2(x_conv1)
         x_conv3 = self.conv3(x_conv2)
-        x_conv4 = self.conv4(x_conv3)
-        x_conv4 = x_conv4.dense()
+        x_conv4 = self.conv4(x_conv3).dense()
+        batch_dict[p + '_sparse_stages'] = (x_conv1, x_conv2, x_conv3)
+        return x_conv4
+
+    def forward(self, batch_dict):
+        p = self.IN_PREFIX
+        x_conv4 = self.forward_sparse(batch_dict)
+        x_conv1, x_conv2, x_conv3 = batch_dict.pop(p + '_sparse_stages')
         x_conv5 = self.conv5(x_conv4)
         batch_dict.update({p + 'multi_scale_2d_features': {
             'x_conv1': x_conv1, 'x_conv2': x_conv2, 'x_conv3': x_conv3, 'x_conv4': x_conv4, 'x_conv5': x_conv5}})

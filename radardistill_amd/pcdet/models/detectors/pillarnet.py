@@ -24,9 +24,52 @@ class PillarNet(Detector3DTemplate):
         # (pillarnet.py:65-73).  Kept on by default for fidelity; MODEL.SKIP_UNUSED_TEACHER_HEAD: True drops that dead work.
         self.skip_unused_teacher_head = bool(self.model_cfg.get('SKIP_UNUSED_TEACHER_HEAD', False))
 
+    def _forward_dense_graph(self, batch_dict, dev):
+        """Training forward with the static dense section replayed as one HIP graph (radardistill_amd/graphs.py): VFE and the four
+        sparse stages of both branches run eagerly as in forward(), everything after `x_conv4.dense()` -- conv5, DenseEnc, CMA,
+        heads, targets, losses and their backward -- is one graph launch."""
+        from radardistill_amd import autograd as A
+        from radardistill_amd import graphs as G
+        A.begin_step(dev)
+        if os.environ.get('RD_GEOM_STREAM', '1') != '0':
+            self._geometry_prelude(batch_dict, dev)
+        main = torch.cuda.current_stream(dev)
+        fork = self.model_cfg.get('TEACHER_STREAM', True) and os.environ.get('RD_TEACHER_STREAM', '1') != '0'
+        if fork and getattr(self, '_teacher_stream', None) is None:
+            self._teacher_stream = torch.cuda.Stream(dev, priority=int(os.environ.get('RD_TEACHER_PRIO', '0')))
+        side = self._teacher_stream if fork else None
+        for m in (self.vfe, self.backbone_3d, self.backbone_2d, self.dense_head):
+            if m is not None and m.training:
+                m.eval()
+        with torch.no_grad():
+            batch_dict = self.vfe(batch_dict)
+        batch_dict = self.radar_vfe(batch_dict)
+        self.backbone_3d.prepare(batch_dict)
+        self.radar_backbone_3d.prepare(batch_dict)
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side), torch.no_grad():
+                t4 = self.backbone_3d.forward_sparse(batch_dict)
+        else:
+            with torch.no_grad():
+                t4 = self.backbone_3d.forward_sparse(batch_dict)
+        s4 = self.radar_backbone_3d.forward_sparse(batch_dict)
+        if side is not None:
+            main.wait_stream(side)
+            t4.record_stream(main)
+        A.end_forward()                       # the sparse stages' BatchNorm counters; the section's own are part of the graph
+        if getattr(self, '_dense_section', None) is None:
+            self._dense_section = G.DenseSection(self)
+        loss, tb_dict = self._dense_section.run(t4, s4, batch_dict['gt_boxes'])
+        return {'loss': loss}, tb_dict, {}
+
     def forward(self, batch_dict):
         from radardistill_amd import autograd as A
         dev = next(self.parameters()).device
+        if dev.type == "cuda" and self.training and self.model_cfg.get('DISTILL', None) and '_teacher_done' not in batch_dict:
+            from radardistill_amd import graphs as G
+            if G.enabled(self.model_cfg):
+                return self._forward_dense_graph(batch_dict, dev)
         if dev.type == "cuda":
             A.begin_step(dev)
         prepared = False

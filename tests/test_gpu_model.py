@@ -1002,3 +1002,58 @@ def test_afd_nan_edge_gradient_contract():
     defined = 3e-4 * (F.mse_loss(rr, lid, reduction="none") * m_ar).sum() / 2 * 2.5 + F.l1_loss(torch.sigmoid(radar_sum), lidar_mask) * 2.5
     defined.backward()
     close(rd.grad, rr.grad, rtol=1e-3, atol=1e-6 * float(rr.grad.abs().max()), what="AFD gradient in the NaN edge")
+
+
+def test_dense_graph_replay_is_bit_identical_to_the_eager_step():
+    """MODEL.DENSE_GRAPH: the static dense section (conv5, DenseEnc, CMA, heads, targets, losses + backward) replayed as ONE HIP graph
+    against the eager path: three optimizer steps over two alternating batches (different point counts, different numbers of boxes)
+    with the library's reductions in fixed order -> every loss term, every gradient and every updated parameter bit-identical."""
+    import os
+    from radardistill_amd import kernels as K
+    from radardistill_amd.pcdet.models import model_fn_decorator
+    from radardistill_amd.train import build_optimizer, build_scheduler
+    grid, B = 128, 2
+    # (sparse LiDAR sweeps: with every 8x cell LiDAR-active the AFD term is NaN by definition, which compares unequal to itself)
+    batches = [make_batch(batch_size=B, n_lidar=300, n_radar=700, n_boxes=nb, grid=grid, seed=s_) for s_, nb in ((5, 10), (6, 17))]
+    fn = model_fn_decorator()
+
+    def run(graph):
+        model, cfg, pc_range, voxel, gs = _build_pillarnet(grid)
+        sd = model.state_dict(); seeded_fill_(sd, seed=77); model.load_state_dict(sd)
+        model = model.to(DEV)
+        model.model_cfg['DENSE_GRAPH'] = graph
+        opt = build_optimizer(model, cfg.OPTIMIZATION)
+        sched, _ = build_scheduler(opt, 10, 1, -1, cfg.OPTIMIZATION)
+        out = []
+        model.train()
+        for it in range(3):
+            sched.step(it)
+            opt.zero_grad()
+            loss, tb, _ = fn(model, {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in batches[it % 2].items()})
+            loss.backward()
+            grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+            opt.step()
+            torch.cuda.synchronize()
+            out.append((loss.detach().clone(), {k: torch.as_tensor(v).detach().clone() for k, v in tb.items()}, grads,
+                        {k: v.detach().clone() for k, v in model.state_dict().items()}))
+        return out
+
+    prev = os.environ.pop("RD_DENSE_GRAPH", None)
+    K.set_deterministic(True)
+    try:
+        eager, graphed = run(False), run(True)
+    finally:
+        K.set_deterministic(False)
+        if prev is not None:
+            os.environ["RD_DENSE_GRAPH"] = prev
+    for it, ((l0, t0, g0, s0), (l1, t1, g1, s1)) in enumerate(zip(eager, graphed)):
+        assert torch.equal(l0, l1) and bool(torch.isfinite(l0)), (it, float(l0), float(l1))
+        assert t0.keys() == t1.keys()
+        for k in t0:
+            a, b = t0[k].float().cpu().reshape(-1), t1[k].float().cpu().reshape(-1)
+            assert torch.equal(a, b) or (bool(torch.isnan(a).all()) and bool(torch.isnan(b).all())), (it, k, a, b)
+        assert g0.keys() == g1.keys(), (it, set(g0) ^ set(g1))
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), (it, "grad", k)
+        for k in s0:
+            assert torch.equal(s0[k], s1[k]), (it, "state", k)
