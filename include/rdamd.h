@@ -156,6 +156,10 @@ typedef struct {
     void *dst;
     int Cout, Cin, taps, kind;
 } rd_layout_job;
+/* jobs_host: HOST array of up to RD_LAYOUT_MULTI_MAX plain (non-split) re-layouts, all done by one launch (the table travels in the
+ * kernel arguments).  Used for the weight gradients of a backward pass (kernel layout -> nn.Conv2d / nn.ConvTranspose2d layout). */
+#define RD_LAYOUT_MULTI_MAX 96
+int rd_weight_layout_multi(const rd_layout_job *jobs_host, int n_jobs, void *stream);
 int rd_weight_layout_split_multi(const rd_layout_job *jobs_dev, const int *chunk_job_dev, const int *chunk_group_dev, int n_chunks, void *stream);
 int rd_conv_fwd_split(const void *in, int in_is_split, int in_rows, int Cin, const void *weight_k, int w_is_split, int taps,
                       const float *bias, float *out, int out_rows, int Cout, const rd_conv_index *idx, const float *scale,

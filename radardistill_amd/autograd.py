@@ -112,6 +112,8 @@ def begin_step(device):
         _OPERANDS.refresh_all(device)
     _BN_TOUCHED.clear()
     _WGRAD_JOIN_QUEUED[0] = False
+    _DEFER_QUEUED[0] = False
+    _DEFERRED_LAYOUT.clear()
 
 
 def end_forward():
@@ -387,6 +389,63 @@ def param_grad_stream(fn, *inputs, param=None):
     return out
 
 
+# Weight gradients leave the GEMM kernels in kernel layout [Cout][taps][Cin]; nn.Conv2d / nn.ConvTranspose2d parameters want
+# [Cout][Cin][kh][kw] / [Cin][Cout][kh][kw].  Instead of one small re-layout launch per layer (49 per step), the destination tensor is
+# handed to autograd EMPTY and all of a backward pass's re-layouts run as ONE launch when the pass ends (engine callback), on the
+# weight-gradient stream before it joins the main stream.  Same precondition as the side stream itself (_side_ok): nothing reads the
+# gradient before the end of the pass -- AccumulateGrad only stores a fresh gradient when the leaf has no .grad yet.
+_DEFERRED_LAYOUT = []
+_DEFER_QUEUED = [False]
+DEFER_LAYOUT = [os.environ.get("RD_DEFER_LAYOUT", "1") != "0"]
+
+
+def _defer_layout_ok(param):
+    return DEFER_LAYOUT[0] and WGRAD_STREAM[0] and param.is_cuda and _side_ok(param)
+
+
+def _flush_deferred_layouts():
+    from .native import LayoutJob
+    jobs, _DEFERRED_LAYOUT[:] = list(_DEFERRED_LAYOUT), []
+    for i in range(0, len(jobs), 96):
+        part = jobs[i:i + 96]
+        arr = (LayoutJob * len(part))()
+        for k, (src, dst_ptr, param, Cout, Cin, taps, kind) in enumerate(part):
+            # where the gradient ended up: AccumulateGrad normally keeps the very tensor backward returned (then .grad IS the deferred
+            # destination); had it cloned instead (an extra reference, a layout mismatch), the clone is what must be filled
+            g = param.grad
+            arr[k].src, arr[k].dst = src.data_ptr(), (g.data_ptr() if g is not None else dst_ptr)
+            arr[k].Cout, arr[k].Cin, arr[k].taps, arr[k].kind = Cout, Cin, taps, kind
+        K.weight_layout_multi(arr, len(part))
+
+
+def defer_weight_layout(gwk, param, Cout, Cin, taps, kind):
+    """-> the (still unwritten) gradient tensor in the parameter's layout; filled by _flush_deferred_layouts at the end of the pass.
+    Called on the weight-gradient stream (inside param_grad_stream) or, without it, on the main stream.  No reference to the
+    returned tensor is kept here: AccumulateGrad only adopts a gradient nobody else holds (it clones otherwise)."""
+    dst = torch.empty(tuple(param.shape), dtype=torch.float32, device=gwk.device)
+    _DEFERRED_LAYOUT.append((gwk, dst.data_ptr(), param, Cout, Cin, taps, kind))
+    if not _DEFER_QUEUED[0]:
+        _DEFER_QUEUED[0] = True
+        dev = gwk.device
+
+        def _finish():
+            _DEFER_QUEUED[0] = False
+            side = _WGRAD_STREAMS.get(dev) if WGRAD_STREAM[0] else None
+            if side is not None:
+                cur = torch.cuda.current_stream(dev)
+                _set_stream(side)
+                try:
+                    _flush_deferred_layouts()
+                finally:
+                    _set_stream(cur)
+                cur.wait_stream(side)
+            else:
+                _flush_deferred_layouts()
+
+        torch.autograd.Variable._execution_engine.queue_callback(_finish)
+    return dst
+
+
 class ConvSpec:
     """Geometry of one convolution call: how output rows find their input rows, forward and backward.
 
@@ -430,8 +489,9 @@ class _ConvFn(torch.autograd.Function):
     or fused BatchNorm statistics (stats) in training."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, spec, Cout, stats):
+    def forward(ctx, x, weight, bias, spec, Cout, stats, bias_feeds_bn=False):
         out = _ConvFn.forward_impl(ctx, x, weight, bias, spec, Cout, stats)
+        ctx.bias_feeds_bn = bool(bias_feeds_bn)
         ctx.save_for_backward(x, weight)
         return out
 
@@ -467,7 +527,7 @@ class _ConvFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         gx, gw, gb = _ConvFn.backward_impl(ctx, x, weight, grad_out.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                                            ctx.needs_input_grad[2])
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None
 
     @staticmethod
     def backward_impl(ctx, x, weight, grad_out, need_x, need_w, need_b):
@@ -513,7 +573,14 @@ class _ConvFn(torch.autograd.Function):
         if need_w:
             gw = param_grad_stream(lambda: _ConvFn._wgrad(ctx, x, weight, grad_out, spec, Cout, Cin), x, grad_out, param=weight)
         if ctx.has_bias and need_b:
-            gb = param_grad_stream(lambda: K.colsum(grad_out) if Cout % 4 == 0 else grad_out.sum(0), grad_out, param=ctx.bias_ref)
+            if getattr(ctx, 'bias_feeds_bn', False):
+                # The conv output goes only into a train-mode BatchNorm, which subtracts the batch mean: d loss / d bias = sum over rows
+                # of the BatchNorm input gradient = gamma * rstd * (sum g - sum g - sum(xhat) * dgamma / n) = 0 identically (sum(xhat)
+                # = 0).  The reference evaluates that sum numerically and gets rounding noise (~1e-7 of the weight gradients); here
+                # it is the exact value, at no launch (was: one column-sum kernel + one stream fork per layer, 45 per step).
+                gb = zeros_accum(Cout, grad_out.device)
+            else:
+                gb = param_grad_stream(lambda: K.colsum(grad_out) if Cout % 4 == 0 else grad_out.sum(0), grad_out, param=ctx.bias_ref)
         return gx, gw, gb
 
     @staticmethod
@@ -527,6 +594,8 @@ class _ConvFn(torch.autograd.Function):
                 gwk = K.conv_wgrad(x, grad_out, spec.taps, spec.fwd_ix, nbr_keepalive=spec.fwd_nbr)         # kernel layout
             if spec.param_kind == 0:
                 gw = gwk.reshape(weight.shape)
+            elif weight.is_leaf and _defer_layout_ok(weight):
+                gw = defer_weight_layout(gwk, weight, Cout, Cin, spec.taps, 4 if spec.param_kind == 1 else 5)
             elif spec.param_kind == 1:
                 gw = K.weight_layout(gwk, Cout, Cin, spec.taps, 4, False, out_shape=tuple(weight.shape))
             else:
@@ -534,8 +603,10 @@ class _ConvFn(torch.autograd.Function):
             return gw
 
 
-def conv(x, weight, bias, spec, Cout, stats=None):
-    return _ConvFn.apply(x, weight, bias, spec, Cout, stats)
+def conv(x, weight, bias, spec, Cout, stats=None, bias_feeds_bn=False):
+    """bias_feeds_bn: the output is consumed only by a train-mode BatchNorm (whose statistics `stats` collects): the bias gradient is
+    then identically zero and no column sum is launched for it."""
+    return _ConvFn.apply(x, weight, bias, spec, Cout, stats, bias_feeds_bn)
 
 
 def conv_inference(x, weight, bias, spec, Cout, scale=None, shift=None, residual=None, relu=False):
@@ -608,6 +679,7 @@ class _ConvBNActFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, spec, Cout, gamma, beta, residual, running_mean, running_var, eps, momentum, act):
         stats = zeros_stats(2 * Cout, x.device)
         raw = _ConvFn.forward_impl(ctx, x, weight, bias, spec, Cout, stats)
+        ctx.bias_feeds_bn = True
         y, mean, rstd, scale, shift = K.bn_train_fwd(raw, stats, gamma, beta, eps, momentum, running_mean, running_var, residual, act)
         ctx.act, ctx.has_res = act, residual is not None
         ctx.save_for_backward(x, weight, raw, y, gamma, mean, rstd, scale, shift)

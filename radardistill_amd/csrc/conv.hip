@@ -748,6 +748,46 @@ extern "C" int rd_weight_layout_split_multi(const rd_layout_job *jobs_dev, const
     return check_launch("rd_weight_layout_split_multi");
 }
 
+// Up to RD_LAYOUT_MULTI_MAX re-layouts in ONE launch, the job table passed by value in the kernel arguments (no device copy of a
+// descriptor table): the ~48 weight gradients of a backward pass leave the GEMMs in kernel layout [Cout][taps][Cin] and all go to
+// their parameters' torch layouts together at the end of the pass.  Block b serves the job whose element range contains b * 1024.
+struct LayoutMulti {
+    rd_layout_job jobs[RD_LAYOUT_MULTI_MAX];
+    int first_block[RD_LAYOUT_MULTI_MAX + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void k_weight_layout_multi(const LayoutMulti t) {
+    int j = 0;
+    while (j + 1 < t.n && (int)blockIdx.x >= t.first_block[j + 1]) ++j;
+    const rd_layout_job job = t.jobs[j];
+    const int64_t total = (int64_t)job.Cout * job.Cin * job.taps;
+    const float *src = reinterpret_cast<const float *>(job.src);
+    float *dst = reinterpret_cast<float *>(job.dst);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = ((int64_t)(blockIdx.x - t.first_block[j]) * 4 + u) * 256 + threadIdx.x;
+        if (i < total) dst[i] = src[layout_src(i, job.Cout, job.Cin, job.taps, job.kind, 0)];
+    }
+}
+
+extern "C" int rd_weight_layout_multi(const rd_layout_job *jobs_host, int n_jobs, void *stream) {
+    RD_REQUIRE(n_jobs >= 0 && n_jobs <= RD_LAYOUT_MULTI_MAX, "rd_weight_layout_multi: at most %d jobs per call", RD_LAYOUT_MULTI_MAX);
+    if (n_jobs == 0) return RD_OK;
+    LayoutMulti t;
+    int blocks = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const rd_layout_job &job = jobs_host[j];
+        RD_REQUIRE(job.kind >= 0 && job.kind <= 8 && job.src && job.dst && job.Cout > 0 && job.Cin > 0 && job.taps > 0, "rd_weight_layout_multi: bad job %d", j);
+        t.jobs[j] = job;
+        t.first_block[j] = blocks;
+        blocks += (int)cdiv((int64_t)job.Cout * job.Cin * job.taps, 1024);
+    }
+    t.first_block[n_jobs] = blocks;
+    t.n = n_jobs;
+    k_weight_layout_multi<<<blocks, 256, 0, S(stream)>>>(t);
+    return check_launch("rd_weight_layout_multi");
+}
+
 extern "C" int rd_weight_layout(const float *src, float *dst, int Cout, int Cin, int taps, int kind, int flip, void *stream) {
     RD_REQUIRE(kind >= 0 && kind <= 8, "rd_weight_layout: bad kind %d", kind);
     int64_t total = (int64_t)Cout * Cin * taps;

@@ -374,6 +374,11 @@ def weight_layout(src, Cout, Cin, taps, kind, flip=False, out_shape=None):
     return dst
 
 
+def weight_layout_multi(jobs, n):
+    """jobs: ctypes array of native.LayoutJob (host); one launch for all of them."""
+    check(native.lib().rd_weight_layout_multi(ctypes.cast(jobs, ctypes.c_void_p), int(n), _stream()), "rd_weight_layout_multi")
+
+
 def colsum(x):
     """Column sums (bias gradients): one launch, per-block partials combined with fp32 atomics into a zero-filled output."""
     _chk(x, f32, "colsum input", 2)

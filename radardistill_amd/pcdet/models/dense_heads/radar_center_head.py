@@ -109,11 +109,13 @@ class _BranchBatch:
         """Teacher: concatenated kernel-layout weights and folded BatchNorm, rebuilt only when a source tensor changes."""
         from radardistill_amd import kernels as K
         src = [t for (_, _, c1, bn, c2, _) in self.branches for t in (c1.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, c2.weight, c2.bias)]
-        ver = (tuple(t._version for t in src), src[0].data_ptr())
+        b3 = K.get_conv_math() == "bf16x3"
+        ver = (tuple(t._version for t in src), src[0].data_ptr(), b3)
         if self.frozen_cache is None or self.frozen_cache[0] != ver:
             with torch.no_grad():
                 w1 = torch.cat([b[2].weight for b in self.branches], 0).contiguous()
-                w1k = K.weight_layout(w1, w1.shape[0], 64, 9, 1)
+                # bf16x3: the operand is kept pre-split like every other frozen weight (the in-kernel split made this one launch 3x slower)
+                w1k = K.weight_layout_split(w1, w1.shape[0], 64, 9, 1) if b3 else K.weight_layout(w1, w1.shape[0], 64, 9, 1)
                 b1 = torch.cat([b[2].bias for b in self.branches]) if self.branches[0][2].bias is not None else None
                 rstd = torch.rsqrt(torch.cat([b[3].running_var for b in self.branches]) + self.branches[0][3].eps)
                 scale = (torch.cat([b[3].weight for b in self.branches]) * rstd).contiguous()
@@ -139,7 +141,8 @@ class _BranchBatch:
         params_frozen = flags[1]
         if (not torch.is_grad_enabled() or (params_frozen and not rows.requires_grad)) and not training:
             w1k, b1, scale, shift, w2, b2 = self._frozen_tensors()
-            y = K.conv_fwd(rows, w1k, 9, b1, rows.shape[0], C1, spec.fwd_ix, scale=scale, shift=shift, relu=True)
+            y = K.conv_fwd(rows, w1k, 9, b1, rows.shape[0], C1, spec.fwd_ix, scale=scale, shift=shift, relu=True,
+                           w_split=K.get_conv_math() == "bf16x3")
             out = K.nconv_fwd(y, w2, b2, B, H, W, self.tab)
         elif training:
             w1 = torch.cat([b[2].weight for b in self.branches], 0)
@@ -148,7 +151,7 @@ class _BranchBatch:
             if b1 is not None:
                 b1._rd_leaves = [b[2].bias for b in self.branches]
             stats = A.zeros_stats(2 * C1, rows.device)
-            raw = A.conv(rows, w1, b1, spec, C1, stats)
+            raw = A.conv(rows, w1, b1, spec, C1, stats, bias_feeds_bn=True)
             gamma = torch.cat([bn.weight for bn in bns])
             beta = torch.cat([bn.bias for bn in bns])
             with torch.no_grad():

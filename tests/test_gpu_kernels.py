@@ -66,9 +66,14 @@ def test_fused_conv_bn_act_node_equals_separate_nodes(act, res):
         out[fused] = [y.detach(), x.grad, conv.weight.grad.clone(), conv.bias.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(),
                       bn.running_mean.clone(), bn.running_var.clone()] + ([r.grad] if res else [])
     for i, (a, b) in enumerate(zip(out[True], out[False])):
-        # entry 3 = gradient of the conv bias in front of the BatchNorm: its true value is 0, what is compared is the rounding noise of
-        # two atomics orders (|values| ~1e-6 against row sums of ~1e2)
-        close(a, b, rtol=1e-5, atol=2e-4 if i == 3 else 1e-5)
+        if i == 3:
+            # gradient of the conv bias in front of the BatchNorm: identically 0 (the BatchNorm subtracts the batch mean).  The fused
+            # node returns the exact value; the separate conv node cannot know about the BatchNorm, sums the rows numerically and gets
+            # rounding noise, ~1e-7 of the weight gradient's scale
+            assert float(a.abs().max()) == 0.0
+            assert float(b.abs().max()) <= 1e-5 * float(out[False][2].abs().max())
+            continue
+        close(a, b, rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("xmajor", [False, True])
