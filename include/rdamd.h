@@ -108,6 +108,22 @@ int rd_vfe_backward(const float *points, int n_points, int n_feat, const int32_t
                     const float *grad_out, const int32_t *argmax, int n_pillars, int n_valid,
                     float *grad_weight, float *grad_gamma, float *grad_beta, float *ws, void *stream);
 
+/* Segmented form of the VFE (vfe_seg.hip; the default path): rd_vfe_group groups the in-range points by pillar (integer counting sort on
+ * point_row: offsets (n_pillars + 1), order (point indices, n_valid of them used); ws: rd_vfe_group_ws_bytes(n_pillars) bytes), then
+ * ONE wavefront per pillar computes the pillar mean, the 9 + C features, Linear, folded BatchNorm, ReLU and the per-pillar max with
+ * wavefront shuffles -- no floating-point atomics, every output written once.  rd_vfe_seg_stats: stats[65] as rd_vfe_linear_stats
+ * (train-mode pass 1); rd_vfe_seg_max: out (P, 32), argmax (P, 32) or NULL (smallest point index wins ties), pillar_acc (P, 4) =
+ * sum x, y, z, count or NULL (rd_vfe_backward reads it).  Replace torch_scatter.scatter_mean / scatter_max and the ~25 ATen kernels of
+ * dynamic_pillar_vfe.py:214-241 like the atomic entries above. */
+int64_t rd_vfe_group_ws_bytes(int n_pillars);
+int rd_vfe_group(const int32_t *point_row, int n_points, int n_pillars, int32_t *offsets, int32_t *order, int32_t *ws, int64_t ws_bytes,
+                 void *stream);
+int rd_vfe_seg_stats(const float *points, int n_feat, const int32_t *order, const int32_t *offsets, const int32_t *coords, const float *weight,
+                     const float *geom, int n_pillars, float *stats, void *stream);
+int rd_vfe_seg_max(const float *points, int n_feat, const int32_t *order, const int32_t *offsets, const int32_t *coords, const float *weight,
+                   const float *geom, const float *scale, const float *shift, int n_pillars, float *out, int32_t *argmax, float *pillar_acc,
+                   void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * C. Convolution as gathered implicit GEMM on the matrix cores (fp32 MFMA).
  *    One kernel family serves

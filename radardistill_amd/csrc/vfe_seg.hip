@@ -1,0 +1,246 @@
+// Pillar VFE, segmented form: points are first GROUPED by pillar (counting sort on the pillar row the voxeliser assigned: integer
+// counts -> exclusive scan -> fill), then ONE wavefront per pillar does everything the reference's ~25 ATen kernels + torch_scatter
+// atomics do (pcdet/models/backbones_3d/vfe/dynamic_pillar_vfe.py:214-241 feature assembly, :14-46 PFNLayerV2): per-pillar mean of
+// xyz, the 9 + C point features, Linear(9+C -> 32), BatchNorm (folded scale / shift), ReLU and the per-pillar max -- with wavefront
+// shuffles for the reductions and NO floating-point atomics: the per-pillar results are written once, coalesced (128 bytes of
+// features per pillar).  See include/rdamd.h section B.
+//
+// Why (round-1 PMC, profiles/round1_pmc_hbm_traffic_f32.json): the first version reduced with one 64-bit atomicMax per (point,
+// channel) into a packed [P][32] u64 buffer that was memset, hammered and unpacked again: 121 MB of HBM traffic per LiDAR launch
+// against 33 MB algorithmic.  Here the point buffer is read once per pass (28-byte rows gathered through the order array; the 6.7 MB
+// buffer is L2-resident), offsets / order add 8 bytes per point, outputs are written once.
+//
+// Lane map of the pillar kernel: lane = (point slot s = lane >> 5, channel c = lane & 31): a wavefront covers two points x 32
+// channels per iteration; each lane keeps its channel's weight row in registers; a point's words are read by 32 lanes at one
+// address (one broadcast transaction).  The two slots are combined with one shuffle.  arg-max rule as before: smallest point index
+// wins ties.  Within a pillar the points are visited in the order the fill pass stored them; rd_set_deterministic(1) sorts every
+// segment by point index first, which makes the mean's summation order (and so every bit downstream) reproducible.
+#include <algorithm>
+#include "common.hpp"
+
+using namespace rd;
+
+namespace {
+
+constexpr int VS_OUT = 32, VS_MAX_IN = 16;
+
+__global__ void k_seg_count(const int32_t *__restrict__ point_row, int n, int32_t *cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && point_row[i] >= 0) atomicAdd(&cnt[point_row[i]], 1);          // integer: exact and order-independent
+}
+
+// exclusive scan of cnt[0..P) -> off[0..P], three launches of 1024-element tiles
+__global__ __launch_bounds__(256) void k_seg_scan_local(const int32_t *__restrict__ cnt, int32_t *off, int32_t *tile_sum, int P) {
+    __shared__ int32_t ws[4];
+    const int base = blockIdx.x * 1024 + threadIdx.x * 4;
+    int32_t v[4], s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        v[k] = base + k < P ? cnt[base + k] : 0;
+        s += v[k];
+    }
+    int32_t incl = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int32_t t = __shfl_up(incl, d, 64);
+        if ((int)(threadIdx.x & 63) >= d) incl += t;
+    }
+    if ((threadIdx.x & 63) == 63) ws[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int32_t wbase = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wbase += ws[w];
+    int32_t run = wbase + incl - s;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (base + k < P) off[base + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == 255) tile_sum[blockIdx.x] = wbase + incl;
+}
+__global__ void k_seg_scan_tiles(int32_t *tile_sum, int n_tiles, int32_t *total_out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {          // <= a few hundred tiles
+        int32_t run = 0;
+        for (int t = 0; t < n_tiles; ++t) {
+            const int32_t v = tile_sum[t];
+            tile_sum[t] = run;
+            run += v;
+        }
+        *total_out = run;
+    }
+}
+__global__ void k_seg_scan_add(int32_t *off, const int32_t *__restrict__ tile_sum, int P) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P) off[i] += tile_sum[i >> 10];
+}
+__global__ void k_seg_fill(const int32_t *__restrict__ point_row, int n, const int32_t *__restrict__ off, int32_t *cursor, int32_t *order) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r = point_row[i];
+    if (r < 0) return;
+    order[off[r] + atomicAdd(&cursor[r], 1)] = i;
+}
+// rd_set_deterministic(1): ascending point index inside every segment (one lane per pillar, insertion sort: segments are short)
+__global__ void k_seg_sort(const int32_t *__restrict__ off, int P, int32_t *order) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int b = off[p], e = off[p + 1];
+    for (int i = b + 1; i < e; ++i) {
+        const int32_t v = order[i];
+        int j = i - 1;
+        while (j >= b && order[j] > v) {
+            order[j + 1] = order[j];
+            --j;
+        }
+        order[j + 1] = v;
+    }
+}
+
+struct SegArgs {
+    const float *points;
+    int n_feat;
+    const int32_t *order, *off, *coords;
+    const float *weight, *geom, *scale, *shift;
+    int P;
+    float *out;
+    int32_t *argmax;
+    float *acc;        // [P][4] sum x, y, z, count (the backward kernels read it)
+    float *stats;      // [65] sum, sum of squares per channel, count (STATS pass)
+};
+
+// MODE 0: statistics of the Linear outputs (train-mode BatchNorm, pass 1); MODE 1: affine + ReLU + per-pillar max (+ arg-max, + acc)
+template <int NF, int MODE>
+__global__ __launch_bounds__(256) void k_vfe_seg(const SegArgs a) {
+    __shared__ float red[2][4][VS_OUT];
+    constexpr int CIN = 9 + NF, STR = 1 + NF;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane >> 5, c = lane & 31;
+    float w[CIN];
+#pragma unroll
+    for (int k = 0; k < CIN; ++k) w[k] = a.weight[c * CIN + k];
+    const float vx = a.geom[0], vy = a.geom[1], xoff = a.geom[3], yoff = a.geom[4], zoff = a.geom[5], x0 = a.geom[6], y0 = a.geom[7], z0 = a.geom[8];
+    const float sc = MODE == 1 ? a.scale[c] : 1.f, sh = MODE == 1 ? a.shift[c] : 0.f;
+    float s1 = 0.f, s2 = 0.f, n_pts = 0.f;
+    for (int p = blockIdx.x * 4 + wave; p < a.P; p += gridDim.x * 4) {
+        const int beg = a.off[p], k = a.off[p + 1] - beg;
+        // ---- per-pillar sum of xyz: lanes take points lane, lane + 64, ...; butterfly over the wavefront
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int j = lane; j < k; j += 64) {
+            const float *q = a.points + (int64_t)a.order[beg + j] * STR;
+            sx += q[1]; sy += q[2]; sz += q[3];
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            sx += __shfl_xor(sx, d, 64);
+            sy += __shfl_xor(sy, d, 64);
+            sz += __shfl_xor(sz, d, 64);
+        }
+        const float cntf = fmaxf((float)k, 1.f);
+        const float mx = sx / cntf, my = sy / cntf, mz = sz / cntf;
+        const int32_t *cd = a.coords + (int64_t)p * 3;          // (b, y, x)
+        const float cxc = (float)cd[2] * vx + xoff, cyc = (float)cd[1] * vy + yoff;
+        float best = 0.f;
+        int besti = 0x7fffffff;
+        for (int j = slot; j < k; j += 2) {
+            const int i = a.order[beg + j];
+            const float *q = a.points + (int64_t)i * STR;
+            float f[CIN];
+            const float x = q[1], y = q[2], z = q[3];
+            f[0] = x - cxc; f[1] = y - cyc; f[2] = z - zoff;
+#pragma unroll
+            for (int t = 0; t < NF; ++t) f[3 + t] = q[1 + t];
+            f[3 + NF] = x - mx; f[4 + NF] = y - my; f[5 + NF] = z - mz;
+            f[6 + NF] = x - x0; f[7 + NF] = y - y0; f[8 + NF] = z - z0;
+            float v = 0.f;
+#pragma unroll
+            for (int t = 0; t < CIN; ++t) v = fmaf(f[t], w[t], v);
+            if (MODE == 0) {
+                s1 += v;
+                s2 += v * v;
+                if (c == 0) n_pts += 1.f;
+            } else {
+                v = fmaxf(fmaf(v, sc, sh), 0.f);
+                if (v > best || (v == best && i < besti)) { best = v; besti = i; }
+            }
+        }
+        if (MODE == 1) {
+            const float ob = __shfl_xor(best, 32, 64);
+            const int oi = __shfl_xor(besti, 32, 64);
+            if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+            if (slot == 0) {
+                a.out[(int64_t)p * VS_OUT + c] = best;
+                if (a.argmax) a.argmax[(int64_t)p * VS_OUT + c] = besti;
+            }
+            if (lane == 0 && a.acc) *reinterpret_cast<float4 *>(a.acc + (int64_t)p * 4) = make_float4(sx, sy, sz, (float)k);
+        }
+    }
+    if (MODE == 0) {
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        n_pts += __shfl_xor(n_pts, 32, 64);
+        if (slot == 0) { red[0][wave][c] = s1; red[1][wave][c] = s2; }
+        __syncthreads();
+        if (threadIdx.x < VS_OUT) {
+            const int cc = threadIdx.x;
+            atomicAdd(&a.stats[cc], red[0][0][cc] + red[0][1][cc] + red[0][2][cc] + red[0][3][cc]);
+            atomicAdd(&a.stats[VS_OUT + cc], red[1][0][cc] + red[1][1][cc] + red[1][2][cc] + red[1][3][cc]);
+        }
+        if (lane == 0 && n_pts != 0.f) atomicAdd(&a.stats[2 * VS_OUT], n_pts);
+    }
+}
+
+#define VS_DISPATCH(NF, ...)                                    \
+    switch (NF) {                                              \
+        case 3: { constexpr int NFC = 3; __VA_ARGS__; } break; \
+        case 4: { constexpr int NFC = 4; __VA_ARGS__; } break; \
+        case 5: { constexpr int NFC = 5; __VA_ARGS__; } break; \
+        case 6: { constexpr int NFC = 6; __VA_ARGS__; } break; \
+        case 7: { constexpr int NFC = 7; __VA_ARGS__; } break; \
+        default: rd::set_error("unsupported n_feat %d (3..7)", NF); return RD_EINVAL; \
+    }
+
+}  // namespace
+
+extern "C" int64_t rd_vfe_group_ws_bytes(int n_pillars) { return ((int64_t)n_pillars + cdiv(std::max(n_pillars, 1), 1024) + 8) * 4; }
+
+// point_row (n_points) -> offsets (n_pillars + 1) and order (n_valid point indices grouped by pillar).  ws: rd_vfe_group_ws_bytes.
+extern "C" int rd_vfe_group(const int32_t *point_row, int n_points, int n_pillars, int32_t *offsets, int32_t *order, int32_t *ws, int64_t ws_bytes,
+                            void *stream) {
+    RD_REQUIRE(n_points >= 0 && n_pillars >= 0 && ws_bytes >= rd_vfe_group_ws_bytes(n_pillars), "rd_vfe_group: bad sizes / workspace too small");
+    hipStream_t st = S(stream);
+    if (n_pillars == 0) return RD_OK;
+    int32_t *cursor = ws, *tile_sum = ws + n_pillars;
+    const int n_tiles = (int)cdiv(n_pillars, 1024);
+    RD_HIP(hipMemsetAsync(ws, 0, (size_t)n_pillars * 4, st));                     // counts, later the fill cursors
+    if (n_points > 0) k_seg_count<<<cdiv(n_points, 256), 256, 0, st>>>(point_row, n_points, cursor);
+    k_seg_scan_local<<<n_tiles, 256, 0, st>>>(cursor, offsets, tile_sum, n_pillars);
+    k_seg_scan_tiles<<<1, 64, 0, st>>>(tile_sum, n_tiles, offsets + n_pillars);
+    k_seg_scan_add<<<cdiv(n_pillars, 256), 256, 0, st>>>(offsets, tile_sum, n_pillars);
+    RD_HIP(hipMemsetAsync(cursor, 0, (size_t)n_pillars * 4, st));
+    if (n_points > 0) k_seg_fill<<<cdiv(n_points, 256), 256, 0, st>>>(point_row, n_points, offsets, cursor, order);
+    if (g_deterministic) k_seg_sort<<<cdiv(n_pillars, 256), 256, 0, st>>>(offsets, n_pillars, order);
+    return check_launch("rd_vfe_group");
+}
+
+// stats[65] = per-channel sum / sum of squares of the Linear outputs over all grouped points, and their count
+extern "C" int rd_vfe_seg_stats(const float *points, int n_feat, const int32_t *order, const int32_t *offsets, const int32_t *coords,
+                                const float *weight, const float *geom, int n_pillars, float *stats, void *stream) {
+    RD_REQUIRE(9 + n_feat <= VS_MAX_IN, "rd_vfe_seg_stats: 9 + n_feat = %d exceeds %d", 9 + n_feat, VS_MAX_IN);
+    hipStream_t st = S(stream);
+    RD_HIP(hipMemsetAsync(stats, 0, 65 * 4, st));
+    if (n_pillars <= 0) return RD_OK;
+    SegArgs a{points, n_feat, order, offsets, coords, weight, geom, nullptr, nullptr, n_pillars, nullptr, nullptr, nullptr, stats};
+    const int blocks = g_deterministic ? 1 : (int)std::min<int64_t>(cdiv(n_pillars, 4), 2048);
+    VS_DISPATCH(n_feat, k_vfe_seg<NFC, 0><<<blocks, 256, 0, st>>>(a));
+    return check_launch("rd_vfe_seg_stats");
+}
+
+// out (P, 32) = max over the pillar's points of relu(Linear * scale + shift); argmax (P, 32) point indices or NULL; acc (P, 4) or NULL
+extern "C" int rd_vfe_seg_max(const float *points, int n_feat, const int32_t *order, const int32_t *offsets, const int32_t *coords,
+                              const float *weight, const float *geom, const float *scale, const float *shift, int n_pillars, float *out,
+                              int32_t *argmax, float *pillar_acc, void *stream) {
+    RD_REQUIRE(9 + n_feat <= VS_MAX_IN, "rd_vfe_seg_max: 9 + n_feat = %d exceeds %d", 9 + n_feat, VS_MAX_IN);
+    if (n_pillars <= 0) return RD_OK;
+    SegArgs a{points, n_feat, order, offsets, coords, weight, geom, scale, shift, n_pillars, out, argmax, pillar_acc, nullptr};
+    const int blocks = (int)std::min<int64_t>(cdiv(n_pillars, 4), 8192);
+    VS_DISPATCH(n_feat, k_vfe_seg<NFC, 1><<<blocks, 256, 0, S(stream)>>>(a));
+    return check_launch("rd_vfe_seg_max");
+}

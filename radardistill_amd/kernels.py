@@ -144,6 +144,46 @@ def vfe_linear_bn_relu_max(points, point_row, coords, acc, weight, geom, scale, 
     return out, argmax
 
 
+def vfe_group(point_row, n_pillars):
+    """Group the in-range points by pillar -> (offsets (P + 1,), order (n_points,)) int32 (vfe_seg.hip)."""
+    _chk(point_row, i32, "point_row", 1)
+    n = point_row.shape[0]
+    dev = point_row.device
+    offsets = torch.empty(n_pillars + 1, dtype=i32, device=dev)
+    order = torch.empty(max(n, 1), dtype=i32, device=dev)
+    nb = native.lib().rd_vfe_group_ws_bytes(int(n_pillars))
+    ws = torch.empty(nb // 4, dtype=i32, device=dev)
+    check(native.lib().rd_vfe_group(_p(point_row), n, int(n_pillars), _p(offsets), _p(order), _p(ws), nb, _stream()), "rd_vfe_group")
+    return offsets, order
+
+
+def _vfe_seg_chk(points, coords, weight, n_pillars):
+    _chk(points, f32, "points", 2); _chk(coords, i32, "coords", 2); _chk(weight, f32, "vfe weight", 2)
+    if weight.shape != (32, 9 + points.shape[1] - 1) or coords.shape != (n_pillars, 3):
+        raise RuntimeError(f"vfe: weight {tuple(weight.shape)} / coords {tuple(coords.shape)} do not match {points.shape[1] - 1} point features, {n_pillars} pillars")
+
+
+def vfe_seg_stats(points, order, offsets, coords, weight, geom, n_pillars):
+    _vfe_seg_chk(points, coords, weight, n_pillars)
+    stats = torch.empty(65, dtype=f32, device=points.device)
+    check(native.lib().rd_vfe_seg_stats(_p(points), points.shape[1] - 1, _p(order), _p(offsets), _p(coords), _p(weight), _p(geom), int(n_pillars),
+                                        _p(stats), _stream()), "rd_vfe_seg_stats")
+    return stats
+
+
+def vfe_seg_max(points, order, offsets, coords, weight, geom, scale, shift, n_pillars, want_argmax):
+    """-> (out (P, 32), argmax (P, 32) or None, acc (P, 4) sum xyz + count)."""
+    _vfe_seg_chk(points, coords, weight, n_pillars)
+    dev = points.device
+    out = torch.empty((n_pillars, 32), dtype=f32, device=dev)
+    argmax = torch.empty((n_pillars, 32), dtype=i32, device=dev) if want_argmax else None
+    acc = torch.empty((n_pillars, 4), dtype=f32, device=dev)
+    check(native.lib().rd_vfe_seg_max(_p(points), points.shape[1] - 1, _p(order), _p(offsets), _p(coords), _p(weight), _p(geom),
+                                      _p(_chk(scale, f32, "scale")), _p(_chk(shift, f32, "shift")), int(n_pillars), _p(out), _p(argmax), _p(acc),
+                                      _stream()), "rd_vfe_seg_max")
+    return out, argmax, acc
+
+
 def vfe_backward(points, point_row, coords, acc, weight, geom, mean, rstd, gamma, beta, grad_out, argmax, n_valid):
     n, nf = points.shape[0], points.shape[1] - 1
     P = grad_out.shape[0]

@@ -66,6 +66,10 @@ SIGNATURES = {
     "rd_vfe_linear_stats": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "rd_vfe_linear_bn_relu_max": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
     "rd_vfe_backward": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
+    "rd_vfe_group_ws_bytes": (c_i64, [c_int]),
+    "rd_vfe_group": (c_int, [_P, c_int, c_int, _P, _P, _P, c_i64, _P]),
+    "rd_vfe_seg_stats": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, _P, _P]),
+    "rd_vfe_seg_max": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
     "rd_conv_fwd": (c_int, [_P, c_int, c_int, _P, c_int, _P, _P, c_int, c_int, ctypes.POINTER(ConvIndex), _P, _P, _P, c_int, _P, _P]),
     "rd_set_conv_math": (c_int, [c_int]),
     "rd_get_conv_math": (c_int, []),

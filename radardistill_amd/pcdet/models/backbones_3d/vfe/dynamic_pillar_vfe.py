@@ -6,6 +6,8 @@ Radar_DynamicPillarVFESimple2D) and :14-46 (PFNLayerV2), but the ~25 ATen kernel
 torch_scatter atomics of the reference become: voxelise into a rank grid (no sort), per-pillar mean, and ONE fused
 Linear -> BatchNorm -> ReLU -> per-pillar max kernel (two passes in training, for the batch statistics).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -30,9 +32,13 @@ class PFNLayerV2(nn.Module):
 
 class _PillarVFEFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, weight, gamma, beta, points, point_row, coords, acc, geom, scale, shift, mean, rstd, n_pillars, n_valid):
+    def forward(ctx, weight, gamma, beta, points, point_row, coords, acc, geom, scale, shift, mean, rstd, n_pillars, n_valid, order=None,
+                offsets=None):
         need_grad = mean is not None
-        out, argmax = K.vfe_linear_bn_relu_max(points, point_row, coords, acc, weight.detach(), geom, scale, shift, n_pillars, need_grad)
+        if order is not None:          # segmented path: the per-pillar sums come out of the same pass
+            out, argmax, acc = K.vfe_seg_max(points, order, offsets, coords, weight.detach().contiguous(), geom, scale, shift, n_pillars, need_grad)
+        else:
+            out, argmax = K.vfe_linear_bn_relu_max(points, point_row, coords, acc, weight.detach(), geom, scale, shift, n_pillars, need_grad)
         if need_grad:
             ctx.save_for_backward(weight, gamma, beta, points, point_row, coords, acc, geom, mean, rstd, argmax)
             ctx.n_valid = n_valid
@@ -43,7 +49,7 @@ class _PillarVFEFn(torch.autograd.Function):
         weight, gamma, beta, points, point_row, coords, acc, geom, mean, rstd, argmax = ctx.saved_tensors
         gw, gg, gb = K.vfe_backward(points, point_row, coords, acc, weight.detach(), geom, mean, rstd, gamma.detach(), beta.detach(),
                                     grad_out.contiguous(), argmax, ctx.n_valid)
-        return (gw, gg, gb) + (None,) * 11
+        return (gw, gg, gb) + (None,) * 13
 
 
 class DynamicPillarVFESimple2D(VFETemplate):
@@ -118,9 +124,14 @@ class DynamicPillarVFESimple2D(VFETemplate):
         points, rg, point_row, coords, P, n_valid = geo
         B = int(batch_dict['batch_size'])
         g = self._geom
-        acc = K.vfe_pillar_mean(points, point_row, P)
         pfn = self.pfn_layers[0]
         w, bn = pfn.linear.weight, pfn.norm
+        # default: points grouped by pillar, one wavefront per pillar, shuffle reductions, no float atomics (vfe_seg.hip);
+        # RD_VFE_SEG=0: the first version (per-point lanes + 64-bit atomicMax into a packed buffer)
+        seg = P > 0 and os.environ.get("RD_VFE_SEG", "1") != "0"
+        if seg:
+            return self._forward_segmented(batch_dict, points, point_row, coords, P, n_valid, g, w, bn)
+        acc = K.vfe_pillar_mean(points, point_row, P)
         if P == 0:
             feats = points.new_zeros((0, 32))
         elif bn.training:
@@ -142,6 +153,33 @@ class DynamicPillarVFESimple2D(VFETemplate):
         batch_dict[self.OUT_PREFIX + 'pillar_features'] = feats
         batch_dict[self.OUT_PREFIX + 'pillar_coords'] = coords
         return batch_dict
+
+
+def _segmented(self, batch_dict, points, point_row, coords, P, n_valid, g, w, bn):
+    offsets, order = K.vfe_group(point_row, P)
+    wd = w.detach().contiguous()
+    if bn.training:
+        stats = K.vfe_seg_stats(points, order, offsets, coords, wd, g, P)
+        if n_valid <= 1:
+            raise ValueError("Expected more than 1 value per channel when training")
+        A._BN_TOUCHED.append(bn)
+        mean, rstd, scale, shift = K.bn_finalize(stats, n_valid, 32, bn.weight.detach(), bn.bias.detach(), float(bn.eps),
+                                                 float(bn.momentum), bn.running_mean, bn.running_var)
+        if torch.is_grad_enabled() and w.requires_grad:
+            feats = _PillarVFEFn.apply(w, bn.weight, bn.bias, points, point_row, coords, None, g, scale, shift, mean, rstd, P, n_valid, order, offsets)
+        else:
+            feats, _, _ = K.vfe_seg_max(points, order, offsets, coords, wd, g, scale, shift, P, False)
+    else:
+        rstd = torch.rsqrt(bn.running_var + bn.eps)
+        scale = (bn.weight * rstd).detach().contiguous()
+        shift = (bn.bias - bn.running_mean * bn.weight * rstd).detach().contiguous()
+        feats, _, _ = K.vfe_seg_max(points, order, offsets, coords, wd, g, scale, shift, P, False)
+    batch_dict[self.OUT_PREFIX + 'pillar_features'] = feats
+    batch_dict[self.OUT_PREFIX + 'pillar_coords'] = coords
+    return batch_dict
+
+
+DynamicPillarVFESimple2D._forward_segmented = _segmented
 
 
 class Radar_DynamicPillarVFESimple2D(DynamicPillarVFESimple2D):
