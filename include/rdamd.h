@@ -306,6 +306,15 @@ int rd_opt_chunk_elems(void);   /* elements per chunk of the chunk table */
  * Data parallelism: rd_pack_grads gathers every t.grad into ONE flat buffer laid out like the moment buffers (tensor t at element
  * offset t.exp_avg - tensors[0].exp_avg); after the all-reduce (SUM) of that buffer, pass it as flat_grad with grad_scale =
  * 1 / world size to the two entries below (flat_grad = NULL, grad_scale = 1: gradients are read from t.grad). */
+/* One bucket of the overlapped exchange: up to RD_PACK_LIST_MAX (src, dst, numel) copies in one launch, the list (HOST memory) travels
+ * in the kernel arguments; src NULL packs zeros (no gradient on this rank). */
+#define RD_PACK_LIST_MAX 128
+typedef struct {
+    const float *src;
+    float *dst;
+    int64_t numel;
+} rd_pack_job;
+int rd_pack_grads_list(const rd_pack_job *jobs_host, int n_jobs, void *stream);
 int rd_pack_grads(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, float *flat, void *stream);
 int rd_grad_norm(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, float max_norm, float *out2, float *ws,
                  int64_t ws_bytes, const float *flat_grad, float grad_scale, void *stream);

@@ -116,6 +116,39 @@ __global__ __launch_bounds__(256) void k_pack_grads(const rd_opt_tensor *__restr
     for (int64_t i = threadIdx.x; i < n; i += 256) d[i] = g[i];
 }
 
+// The same copy for an explicit list of (source, destination, count) triples passed BY VALUE in the kernel arguments: one bucket of
+// the overlapped data-parallel exchange is packed the moment its last gradient exists, without a device-resident descriptor table.
+struct PackList {
+    rd_pack_job jobs[RD_PACK_LIST_MAX];
+    int first_block[RD_PACK_LIST_MAX + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void k_pack_list(const PackList t) {
+    int j = 0;
+    while (j + 1 < t.n && (int)blockIdx.x >= t.first_block[j + 1]) ++j;
+    const rd_pack_job job = t.jobs[j];
+    const int64_t base = (int64_t)(blockIdx.x - t.first_block[j]) * OPT_CHUNK;
+    const int64_t n = min((int64_t)OPT_CHUNK, job.numel - base);
+    for (int64_t i = threadIdx.x; i < n; i += 256) job.dst[base + i] = job.src ? job.src[base + i] : 0.f;
+}
+
+extern "C" int rd_pack_grads_list(const rd_pack_job *jobs_host, int n_jobs, void *stream) {
+    RD_REQUIRE(n_jobs >= 0 && n_jobs <= RD_PACK_LIST_MAX, "rd_pack_grads_list: at most %d tensors per call", RD_PACK_LIST_MAX);
+    if (n_jobs == 0) return RD_OK;
+    PackList t;
+    int blocks = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        RD_REQUIRE(jobs_host[j].dst && jobs_host[j].numel > 0, "rd_pack_grads_list: bad job %d", j);
+        t.jobs[j] = jobs_host[j];
+        t.first_block[j] = blocks;
+        blocks += (int)cdiv(jobs_host[j].numel, OPT_CHUNK);
+    }
+    t.first_block[n_jobs] = blocks;
+    t.n = n_jobs;
+    k_pack_list<<<blocks, 256, 0, S(stream)>>>(t);
+    return check_launch("rd_pack_grads_list");
+}
+
 extern "C" int rd_pack_grads(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, float *flat, void *stream) {
     RD_REQUIRE(flat != nullptr, "rd_pack_grads: flat buffer is NULL");
     if (n_chunks <= 0) return RD_OK;

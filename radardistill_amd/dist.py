@@ -77,6 +77,51 @@ def data_parallel(model, optimizer, device_index=None, mode=None):
     return model
 
 
+class GradBuckets:
+    """Bucketed, overlapped gradient exchange over ONE flat fp32 buffer (99.6 MB, bucketed in reverse module order and
+    overlapped with the student backward).  The buffer is laid out in parameter order; buckets are contiguous parameter ranges of
+    ~`bucket_bytes`, built from the LAST parameter backwards -- backward produces the head's gradients first and the VFE's last, so
+    bucket 0 (head) is complete first.  `ready(i)` is called once per parameter and backward pass (post-accumulate-grad hook); when
+    a bucket's last gradient has arrived, `launch(b)` packs it into its slice and starts its all-reduce (async), while backward
+    continues to produce the earlier layers' gradients.  `finish()` launches whatever is still open (parameters that received no
+    gradient) and waits for all collectives.  Summation order inside a collective does not depend on the bucketing, so the result
+    equals the unbucketed all-reduce bit for bit (tests/test_dist_gloo.py, tests/dist_flat_check.py)."""
+
+    def __init__(self, numels, bucket_bytes=25 << 20):
+        n = len(numels)
+        self.ranges = []                     # (param_lo, param_hi) in parameter order, listed head-first
+        hi, acc = n, 0
+        for i in range(n - 1, -1, -1):
+            acc += numels[i] * 4
+            if acc >= bucket_bytes or i == 0:
+                self.ranges.append((i, hi))
+                hi, acc = i, 0
+        self.bucket_of = [0] * n
+        for b, (lo, hi_) in enumerate(self.ranges):
+            for i in range(lo, hi_):
+                self.bucket_of[i] = b
+        self.reset()
+
+    def reset(self):
+        self.left = [hi - lo for lo, hi in self.ranges]
+        self.launched = [False] * len(self.ranges)
+
+    def ready(self, i):
+        """-> bucket index to launch now, or None."""
+        b = self.bucket_of[i]
+        self.left[b] -= 1
+        if self.left[b] == 0 and not self.launched[b]:
+            self.launched[b] = True
+            return b
+        return None
+
+    def open_buckets(self):
+        out = [b for b, done in enumerate(self.launched) if not done]
+        for b in out:
+            self.launched[b] = True
+        return out
+
+
 def max_over_ranks(seconds, device="cpu"):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(seconds)

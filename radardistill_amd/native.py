@@ -29,6 +29,11 @@ class LayoutJob(ctypes.Structure):
     _fields_ = [("src", c_vp), ("dst", c_vp), ("Cout", c_int), ("Cin", c_int), ("taps", c_int), ("kind", c_int)]
 
 
+class PackJob(ctypes.Structure):
+    """rd_pack_job of include/rdamd.h."""
+    _fields_ = [("src", c_vp), ("dst", c_vp), ("numel", c_i64)]
+
+
 class CenterLossCfg(ctypes.Structure):
     """rd_center_loss_cfg of include/rdamd.h."""
     _fields_ = [("B", c_int), ("H", c_int), ("W", c_int), ("NO", c_int), ("n_heads", c_int), ("n_ch", c_int), ("K", c_int),
@@ -103,6 +108,7 @@ SIGNATURES = {
     "rd_pfd_bwd": (c_int, [_P, _P, _P, _P, c_i64, c_int, _P, _P, _P, _P, _P, _P]),
     "rd_boxes_aligned_overlap_bev": (c_int, [c_int, _P, _P, _P, _P]),
     "rd_opt_chunk_elems": (c_int, []),
+    "rd_pack_grads_list": (c_int, [_P, c_int, _P]),
     "rd_pack_grads": (c_int, [_P, _P, c_int, _P, _P]),
     "rd_grad_norm": (c_int, [_P, _P, c_int, c_f32, _P, _P, c_i64, _P, c_f32, _P]),
     "rd_adam_step": (c_int, [_P, _P, c_int, c_f64, c_f64, c_f64, c_f64, c_f64, c_int, _P, _P, _P, c_f32, _P]),

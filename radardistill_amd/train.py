@@ -100,15 +100,67 @@ class FusedAdamOneCycle:
         self.flat_grad = None          # data parallelism: see enable_flat_allreduce()
         self.process_group = None
 
-    def enable_flat_allreduce(self, process_group=None):
-        """Data-parallel gradient exchange without DistributedDataParallel: after backward ONE launch packs the ~500 gradient
-        tensors into a flat fp32 buffer (laid out like the Adam moments), ONE all-reduce (RCCL over xGMI: 100 MB, ~0.6 ms at
-        8 GPUs) sums it over the ranks, and the norm / Adam kernels read the averaged gradients straight from that buffer --
-        instead of DDP's per-parameter hooks and ~500 bucket-copy launches per step.  Parameters must start equal on all ranks
-        (dist.broadcast_parameters)."""
+    def enable_flat_allreduce(self, process_group=None, bucket_mb=None, overlap=None):
+        """Data-parallel gradient exchange without DistributedDataParallel: the ~500 gradient tensors are packed into a flat fp32
+        buffer (laid out like the Adam moments), summed over the ranks (RCCL over xGMI) and the norm / Adam kernels read the averaged
+        gradients straight from that buffer (flat_grad, grad_scale = 1 / world).  Parameters must start equal on all ranks
+        (dist.broadcast_parameters).
+        overlap (default on, RD_DDP_OVERLAP=0 disables): the buffer is cut into ~bucket_mb (25) MB buckets in reverse parameter order;
+        a post-accumulate-grad hook per parameter counts a bucket down and, when its last gradient exists, packs the bucket (one
+        launch, rd_pack_grads_list) and starts its all-reduce on a communication stream that first waits for the main and the
+        weight-gradient streams -- the head's 7 MB travel while DenseEnc / CMA / SparseEnc are still in their backward.  step()
+        only waits for the collectives.  Without overlap: one pack launch + one all-reduce after backward."""
+        import os
+        from .dist import GradBuckets
         n = int(self.offsets[-1])
         self.flat_grad = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
         self.process_group = process_group
+        if overlap is None:
+            overlap = os.environ.get("RD_DDP_OVERLAP", "1") != "0"
+        self.buckets = None
+        if overlap:
+            mb = float(bucket_mb if bucket_mb is not None else os.environ.get("RD_DDP_BUCKET_MB", "25"))
+            self.buckets = GradBuckets([p.numel() for p in self.params], int(mb * (1 << 20)))
+            self._works = []
+            self._comm_stream = torch.cuda.Stream(self.params[0].device) if self.params[0].is_cuda else None
+            A.DEFER_LAYOUT[0] = False          # a bucket is packed mid-backward: every gradient must be complete when its hook fires
+            for i, p in enumerate(self.params):
+                p.register_post_accumulate_grad_hook(lambda _p, i=i: self._grad_ready(i))
+
+    def _grad_ready(self, i):
+        b = self.buckets.ready(i)
+        if b is not None:
+            self._launch_bucket(b)
+
+    def _launch_bucket(self, b):
+        """Pack bucket b's gradients into its slice of the flat buffer and start the slice's all-reduce."""
+        import torch.distributed as dist
+        from .native import PackJob
+        lo, hi = self.buckets.ranges[b]
+        e0, e1 = int(self.offsets[lo]), int(self.offsets[hi])
+        dev = self.params[0].device
+        comm = self._comm_stream
+        main = torch.cuda.current_stream(dev)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        comm.wait_event(ev)
+        side = A._WGRAD_STREAMS.get(dev)
+        if side is not None:
+            comm.wait_stream(side)                 # weight gradients are produced on the side stream
+        base = self.flat_grad.data_ptr()
+        with torch.cuda.stream(comm):
+            for s in range(lo, hi, 128):
+                part = range(s, min(hi, s + 128))
+                arr = (PackJob * len(part))()
+                for k, i in enumerate(part):
+                    g = self.params[i].grad
+                    if g is not None and (not g.is_contiguous() or g.dtype != torch.float32):
+                        g = self.params[i].grad = g.float().contiguous()
+                    arr[k].src = g.data_ptr() if g is not None else None
+                    arr[k].dst = base + 4 * int(self.offsets[i])
+                    arr[k].numel = self.params[i].numel()
+                check(native.lib().rd_pack_grads_list(ctypes.cast(arr, ctypes.c_void_p), len(part), _stream()), "rd_pack_grads_list")
+            self._works.append(dist.all_reduce(self.flat_grad[e0:e1], op=dist.ReduceOp.SUM, group=self.process_group, async_op=True))
 
     def zero_grad(self):
         for p in self.params:
@@ -163,6 +215,15 @@ class FusedAdamOneCycle:
         if self.flat_grad is None:
             return None, 1.0
         import torch.distributed as dist
+        if getattr(self, 'buckets', None) is not None:
+            for b in self.buckets.open_buckets():          # parameters that received no gradient keep their bucket open until here
+                self._launch_bucket(b)
+            for w in self._works:
+                w.wait()                                   # the current stream waits for the collective
+            torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._comm_stream)
+            self._works = []
+            self.buckets.reset()
+            return self.flat_grad, 1.0 / dist.get_world_size(self.process_group)
         if table is None:
             table = self._fill_table()
         check(native.lib().rd_pack_grads(_p(table), _p(self.chunks_dev), self.n_chunks, _p(self.flat_grad), _stream()), "rd_pack_grads")

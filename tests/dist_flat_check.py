@@ -58,8 +58,11 @@ def main():
     assert scale == 1.0 / world
     assert torch.equal(buf, ref), f"flat buffer differs from the per-tensor all-reduce: max {float((buf - ref).abs().max())}"
     dist.barrier()
+    nb = len(opt.buckets.ranges) if getattr(opt, "buckets", None) is not None else 0
+    if os.environ.get("RD_DDP_OVERLAP", "1") != "0":
+        assert nb >= 2 and all(v == hi - lo for v, (lo, hi) in zip(opt.buckets.left, opt.buckets.ranges)), "bucket bookkeeping not reset"
     if rank == 0:
-        print(f"DIST_FLAT_OK params {flat.numel()} grad_norm {float((buf * scale).norm()):.3f}", flush=True)
+        print(f"DIST_FLAT_OK params {flat.numel()} buckets {nb} grad_norm {float((buf * scale).norm()):.3f}", flush=True)
     dist.destroy_process_group()
 
 

@@ -79,3 +79,69 @@ def test_world_size_2_gloo():
     assert abs(t0 - 0.2) < 1e-9 and abs(t1 - 0.2) < 1e-9     # max over ranks
     assert a0 == a1 == [0.5, 5.0, 1.0]
     assert f0 and f1                                         # frozen parameters received no gradient
+
+
+def _bucket_worker(rank, world, port, q):
+    """GradBuckets on CPU tensors: hooks count buckets down during backward, each complete bucket is packed and all-reduced (async)
+    while backward continues; the result must equal the per-tensor all-reduce bit for bit and the bookkeeping must reset."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from radardistill_amd import dist as D
+    import torch.distributed as dist
+    D.init_distributed(backend="gloo")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(40, 300), torch.nn.ReLU(), torch.nn.Linear(300, 300), torch.nn.ReLU(), torch.nn.Linear(300, 7))
+    unused = torch.nn.Parameter(torch.zeros(11))                       # never receives a gradient: its bucket is closed by finish
+    params = [unused] + list(net.parameters())                         # parameter order = forward order: the unused one sits in the LAST bucket
+    numels = [p.numel() for p in params]
+    offs = np.cumsum([0] + numels)
+    flat = torch.zeros(int(offs[-1]))
+    buckets = D.GradBuckets(numels, bucket_bytes=9_000)
+    assert len(buckets.ranges) >= 3 and sorted(i for lo, hi in buckets.ranges for i in range(lo, hi)) == list(range(len(params)))
+    works, order = [], []
+
+    def launch(b):
+        lo, hi = buckets.ranges[b]
+        for i in range(lo, hi):
+            g = params[i].grad
+            flat[offs[i]:offs[i + 1]] = g.reshape(-1) if g is not None else 0.0
+        works.append(dist.all_reduce(flat[offs[lo]:offs[hi]], async_op=True))
+        order.append(b)
+
+    for i, p in enumerate(params):
+        p.register_post_accumulate_grad_hook(lambda _p, i=i: (lambda b: launch(b) if b is not None else None)(buckets.ready(i)))
+    ok = True
+    for it in range(2):
+        for p in params:
+            p.grad = None
+        works.clear(); order.clear()
+        x = torch.randn(5, 40, generator=torch.Generator().manual_seed(10 * rank + it))
+        net(x).square().sum().backward()
+        in_backward = list(order)                                      # buckets that started before backward returned
+        for b in buckets.open_buckets():
+            launch(b)
+        for w in works:
+            w.wait()
+        buckets.reset()
+        ref = []
+        for p in params:
+            g = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().clone().reshape(-1)
+            dist.all_reduce(g)
+            ref.append(g)
+        ok = ok and torch.equal(flat, torch.cat(ref)) and len(in_backward) >= 2 and in_backward[0] == 0
+    q.put((rank, ok, float(flat.abs().sum())))
+    dist.destroy_process_group()
+
+
+def test_bucketed_overlapped_allreduce_equals_per_tensor_allreduce_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] and res[1][1]
+    assert res[0][2] == res[1][2] and res[0][2] > 0

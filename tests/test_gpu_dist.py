@@ -17,8 +17,13 @@ def _free_port():
     return p
 
 
-def test_flat_allreduce_matches_ddp_two_ranks():
-    env = dict(os.environ, RD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+@pytest.mark.parametrize("overlap,bucket_mb", [("0", "25"), ("1", "25"), ("1", "2")])
+def test_flat_allreduce_matches_ddp_two_ranks(overlap, bucket_mb):
+    """overlap 0: one pack + one all-reduce after backward; overlap 1: bucketed (4 buckets at 25 MB, ~40 at 2 MB), each bucket's
+    all-reduce started from the hook of its last gradient while backward continues -- all three must equal the per-tensor all-reduce
+    of the same gradients bit for bit."""
+    env = dict(os.environ, RD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", RD_DDP_OVERLAP=overlap,
+               RD_DDP_BUCKET_MB=bucket_mb)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_flat_check.py")]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
