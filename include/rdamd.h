@@ -316,16 +316,22 @@ typedef struct {
 } rd_pack_job;
 int rd_pack_grads_list(const rd_pack_job *jobs_host, int n_jobs, void *stream);
 int rd_pack_grads(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, float *flat, void *stream);
+/* inv_loss_scale_dev (NULL = 1): device scalar 1 / S of mixed-precision loss scaling (torch.cuda.amp.GradScaler in
+ * tools/train_utils/train_utils.py:23,57-64): gradients in memory are S times too large, norm and update use g / S.  max_norm <= 0:
+ * no clipping (coefficient 1), the norm is still written (overflow check).  overflow_count_dev (NULL or one int32): incremented when
+ * the norm is not finite; rd_adam_step subtracts it from `step` (a step GradScaler skips is not an Adam step). */
 int rd_grad_norm(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, float max_norm, float *out2, float *ws,
-                 int64_t ws_bytes, const float *flat_grad, float grad_scale, void *stream);
+                 int64_t ws_bytes, const float *flat_grad, float grad_scale, const float *inv_loss_scale_dev, int32_t *overflow_count_dev,
+                 void *stream);
 /* step = 1-based count of optimizer steps (bias correction).  clip_dev may be NULL (no clipping) or out2 of rd_grad_norm.
  * A tensor whose `grad` is NULL sits the step out as in torch.optim.Adam (only the decoupled decay p *= 1 - wd*lr of
  * OptimWrapper.step touches it; rd_grad_norm ignores it, rd_pack_grads packs zeros); skipped_dev (NULL = all zero) holds per tensor
  * how many steps it sat out so far, so that its own bias-correction count is step - skipped[t].  Hyper-parameters are doubles: the
- * reference forms 1 - wd*lr, lr / (1 - beta1^t), sqrt(1 - beta2^t) in Python floats before they meet fp32 tensors. */
+ * reference forms 1 - wd*lr, lr / (1 - beta1^t), sqrt(1 - beta2^t) in Python floats before they meet fp32 tensors.
+ * skip_nonfinite = 1 (GradScaler.step): when clip_dev[0] (the gradient norm) is not finite the launch changes nothing. */
 int rd_adam_step(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, double lr, double beta1, double beta2, double eps,
                  double weight_decay, int step, const int32_t *skipped_dev, const float *clip_dev, const float *flat_grad, float grad_scale,
-                 void *stream);
+                 const float *inv_loss_scale_dev, int skip_nonfinite, const int32_t *overflow_count_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * J. Depthwise KxK convolution on channels-last maps (ConvNeXt dwconv 7x7, groups = C, padding K/2).  Replaces cuDNN's

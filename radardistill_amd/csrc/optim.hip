@@ -20,9 +20,13 @@ __device__ __forceinline__ const float *grad_ptr(const rd_opt_tensor *tensors, c
     return flat ? flat + (t.exp_avg - tensors[0].exp_avg) : t.grad;
 }
 
+// inv_loss_scale (device scalar or NULL): mixed-precision loss scaling (torch.cuda.amp.GradScaler, train_utils.py:23,57-64): the
+// gradients in memory are S times too large; the norm and the Adam update use g / S without a separate unscale pass.
 __global__ __launch_bounds__(256) void k_gradnorm_partial(const rd_opt_tensor *__restrict__ tensors, const int2 *__restrict__ chunks, int n_chunks,
-                                                          const float *__restrict__ flat, float grad_scale, float *partial) {
+                                                          const float *__restrict__ flat, float grad_scale, const float *__restrict__ inv_loss_scale,
+                                                          float *partial) {
     __shared__ float red[4];
+    if (inv_loss_scale) grad_scale *= inv_loss_scale[0];
     const int2 ch = chunks[blockIdx.x];
     const rd_opt_tensor t = tensors[ch.x];
     const float *g = grad_ptr(tensors, t, flat) + ch.y;
@@ -39,7 +43,7 @@ __global__ __launch_bounds__(256) void k_gradnorm_partial(const rd_opt_tensor *_
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ void k_gradnorm_final(const float *partial, int n, float max_norm, float *out /*[2]: total_norm, clip_coef*/) {
+__global__ void k_gradnorm_final(const float *partial, int n, float max_norm, float *out /*[2]: total_norm, clip_coef*/, int32_t *overflow_count) {
     __shared__ double red[256];
     double s = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) s += (double)partial[i];
@@ -52,9 +56,10 @@ __global__ void k_gradnorm_final(const float *partial, int n, float max_norm, fl
     if (threadIdx.x == 0) {
         float total = (float)sqrt(red[0]);
         out[0] = total;
-        float coef = max_norm / (total + 1e-6f);
+        float coef = max_norm > 0.f ? max_norm / (total + 1e-6f) : 1.f;      // max_norm <= 0: norm only (loss-scaling overflow check)
         out[1] = coef < 1.f ? coef : 1.f;       // torch.clamp(max=1.0); NaN total -> NaN coef -> NaN update, as in torch
         if (!(coef == coef)) out[1] = coef;
+        if (overflow_count && !isfinite(total)) overflow_count[0] += 1;      // a step GradScaler skips does not count as an Adam step
     }
 }
 
@@ -65,8 +70,12 @@ __global__ void k_gradnorm_final(const float *partial, int n, float max_norm, fl
 __global__ __launch_bounds__(256) void k_adam(const rd_opt_tensor *__restrict__ tensors, const int2 *__restrict__ chunks, double lr, float beta1,
                                               float beta2, float eps, float decay, float step_size0, float bc2_sqrt0, double beta1d, double beta2d,
                                               int step, const int32_t *__restrict__ skipped, const float *__restrict__ clip,
-                                              const float *__restrict__ flat, float grad_scale) {
+                                              const float *__restrict__ flat, float grad_scale, const float *__restrict__ inv_loss_scale,
+                                              int skip_nonfinite, const int32_t *__restrict__ overflow_count) {
     __shared__ float sh[2];
+    // GradScaler.step: an overflowed step (non-finite gradient norm) leaves parameters, moments and the decoupled decay untouched
+    if (skip_nonfinite && clip && !isfinite(clip[0])) return;
+    if (inv_loss_scale) grad_scale *= inv_loss_scale[0];
     const int2 ch = chunks[blockIdx.x];
     const rd_opt_tensor t = tensors[ch.x];
     const int64_t n = min((int64_t)OPT_CHUNK, t.numel - ch.y);
@@ -76,9 +85,9 @@ __global__ __launch_bounds__(256) void k_adam(const rd_opt_tensor *__restrict__ 
         return;
     }
     float step_size = step_size0, bc2_sqrt = bc2_sqrt0;
-    if (skipped != nullptr) {
+    if (skipped != nullptr || overflow_count != nullptr) {
         if (threadIdx.x == 0) {
-            const int own = step - skipped[ch.x];
+            const int own = step - (skipped ? skipped[ch.x] : 0) - (overflow_count ? overflow_count[0] : 0);
             sh[0] = (float)(lr / (1.0 - pow(beta1d, (double)own)));
             sh[1] = (float)sqrt(1.0 - pow(beta2d, (double)own));
         }
@@ -157,25 +166,29 @@ extern "C" int rd_pack_grads(const rd_opt_tensor *tensors_dev, const int32_t *ch
 }
 
 extern "C" int rd_grad_norm(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, float max_norm, float *out2,
-                            float *ws, int64_t ws_bytes, const float *flat_grad, float grad_scale, void *stream) {
+                            float *ws, int64_t ws_bytes, const float *flat_grad, float grad_scale, const float *inv_loss_scale_dev,
+                            int32_t *overflow_count_dev, void *stream) {
     RD_REQUIRE(n_chunks >= 0 && ws_bytes >= (int64_t)n_chunks * 4, "rd_grad_norm: workspace too small");
     hipStream_t st = S(stream);
     if (n_chunks > 0)
-        k_gradnorm_partial<<<n_chunks, 256, 0, st>>>(tensors_dev, reinterpret_cast<const int2 *>(chunks_dev), n_chunks, flat_grad, grad_scale, ws);
-    k_gradnorm_final<<<1, 256, 0, st>>>(ws, n_chunks, max_norm, out2);
+        k_gradnorm_partial<<<n_chunks, 256, 0, st>>>(tensors_dev, reinterpret_cast<const int2 *>(chunks_dev), n_chunks, flat_grad, grad_scale,
+                                                     inv_loss_scale_dev, ws);
+    k_gradnorm_final<<<1, 256, 0, st>>>(ws, n_chunks, max_norm, out2, overflow_count_dev);
     return check_launch("rd_grad_norm");
 }
 
 extern "C" int rd_adam_step(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, double lr, double beta1, double beta2,
                             double eps, double weight_decay, int step, const int32_t *skipped_dev, const float *clip_dev,
-                            const float *flat_grad, float grad_scale, void *stream) {
+                            const float *flat_grad, float grad_scale, const float *inv_loss_scale_dev, int skip_nonfinite,
+                            const int32_t *overflow_count_dev, void *stream) {
+    RD_REQUIRE(!skip_nonfinite || clip_dev, "rd_adam_step: skip_nonfinite needs the norm of rd_grad_norm (clip_dev)");
     RD_REQUIRE(step >= 1, "rd_adam_step: step must be >= 1");
     if (n_chunks <= 0) return RD_OK;
     // scalars are formed in double like the reference's Python floats and rounded once (torch applies them to fp32 tensors)
     const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
     k_adam<<<n_chunks, 256, 0, S(stream)>>>(tensors_dev, reinterpret_cast<const int2 *>(chunks_dev), lr, (float)beta1, (float)beta2, (float)eps,
                                             (float)(1.0 - weight_decay * lr), (float)(lr / bc1), (float)sqrt(bc2), beta1, beta2, step, skipped_dev,
-                                            clip_dev, flat_grad, grad_scale);
+                                            clip_dev, flat_grad, grad_scale, inv_loss_scale_dev, skip_nonfinite, overflow_count_dev);
     return check_launch("rd_adam_step");
 }
 

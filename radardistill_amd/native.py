@@ -110,8 +110,8 @@ SIGNATURES = {
     "rd_opt_chunk_elems": (c_int, []),
     "rd_pack_grads_list": (c_int, [_P, c_int, _P]),
     "rd_pack_grads": (c_int, [_P, _P, c_int, _P, _P]),
-    "rd_grad_norm": (c_int, [_P, _P, c_int, c_f32, _P, _P, c_i64, _P, c_f32, _P]),
-    "rd_adam_step": (c_int, [_P, _P, c_int, c_f64, c_f64, c_f64, c_f64, c_f64, c_int, _P, _P, _P, c_f32, _P]),
+    "rd_grad_norm": (c_int, [_P, _P, c_int, c_f32, _P, _P, c_i64, _P, c_f32, _P, _P, _P]),
+    "rd_adam_step": (c_int, [_P, _P, c_int, c_f64, c_f64, c_f64, c_f64, c_f64, c_int, _P, _P, _P, c_f32, _P, c_int, _P, _P]),
     "rd_dwconv_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "rd_dwconv_wgrad_ws_bytes": (c_i64, [c_int, c_int, c_int, c_int, c_int]),
     "rd_dwconv_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_i64, _P]),

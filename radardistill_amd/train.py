@@ -230,20 +230,26 @@ class FusedAdamOneCycle:
         dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.process_group)
         return self.flat_grad, 1.0 / dist.get_world_size(self.process_group)
 
-    def step(self):
-        """clip_grad_norm_(grad_clip) + OptimWrapper.step(); returns the device tensor [total_norm, clip_coef]."""
+    def step(self, inv_loss_scale=None, overflow_count=None):
+        """clip_grad_norm_(grad_clip) + OptimWrapper.step(); returns the device tensor [total_norm, clip_coef].
+        inv_loss_scale: device scalar 1 / S when the loss was multiplied by S before backward (AmpScaler): norm and update use g / S
+        and a non-finite norm skips the whole update on the device, as GradScaler.unscale_ / step do (train_utils.py:60-64);
+        overflow_count: device int32 counting the skipped steps (they are not Adam steps: bias correction uses step - overflows)."""
         table = self._fill_table()
         L = native.lib()
         flat, scale = self.allreduce_gradients(table)
         clip = None
-        if self.grad_clip is not None and self.grad_clip > 0:
-            check(L.rd_grad_norm(_p(table), _p(self.chunks_dev), self.n_chunks, float(self.grad_clip), _p(self.norm_out),
-                                 _p(self.ws), self.ws.numel() * 4, _p(flat), scale, _stream()), "rd_grad_norm")
+        amp = inv_loss_scale is not None
+        if amp or (self.grad_clip is not None and self.grad_clip > 0):
+            max_norm = float(self.grad_clip) if (self.grad_clip is not None and self.grad_clip > 0) else 0.0
+            check(L.rd_grad_norm(_p(table), _p(self.chunks_dev), self.n_chunks, max_norm, _p(self.norm_out),
+                                 _p(self.ws), self.ws.numel() * 4, _p(flat), scale, _p(inv_loss_scale), _p(overflow_count), _stream()),
+                  "rd_grad_norm")
             clip = self.norm_out
         self.step_count += 1
         check(L.rd_adam_step(_p(table), _p(self.chunks_dev), self.n_chunks, float(self.lr), float(self.mom), float(self.beta2),
-                             float(self.eps), float(self.wd), self.step_count, _p(self.skipped_dev), _p(clip), _p(flat), scale, _stream()),
-              "rd_adam_step")
+                             float(self.eps), float(self.wd), self.step_count, _p(self.skipped_dev), _p(clip), _p(flat), scale,
+                             _p(inv_loss_scale), int(amp), _p(overflow_count), _stream()), "rd_adam_step")
         absent = [i for i, p in enumerate(self.params) if p.grad is None]
         if absent:                             # they sat this step out: their own Adam step count stays behind from now on
             self.skipped[absent] += 1
@@ -339,14 +345,59 @@ def build_scheduler(optimizer, total_iters_each_epoch, total_epochs, last_epoch,
     return OneCycle(optimizer, total_steps, optim_cfg.LR, list(optim_cfg.MOMS), optim_cfg.DIV_FACTOR, optim_cfg.PCT_START), None
 
 
-def train_step(model, optimizer, lr_scheduler, model_func, batch, accumulated_iter):
-    """One iteration of train_one_epoch (train_utils.py:44-64) without logging: returns (loss tensor, tb_dict)."""
+class AmpScaler:
+    """Dynamic loss scaling of the reference's `--use_amp` path (torch.cuda.amp.GradScaler(init_scale=LOSS_SCALE_FP16 or 2**16),
+    train_utils.py:23,57-64; torch defaults growth 2.0, backoff 0.5, growth interval 2000) without host synchronisation: the scale
+    and the growth counter live on the device; unscale_ + clip + step are the fused optimizer's own launches (g / S inside the norm
+    and Adam kernels, a non-finite norm skips the update); update() is four tiny device ops.
+    The arithmetic of this build's kernels is not changed by autocast (fp32 storage, fp32 / bf16x3 products): what --use_amp keeps
+    here is the loop's control flow and the skipped-step semantics."""
+
+    def __init__(self, device, init_scale=2.0 ** 16, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, enabled=True):
+        self.enabled = bool(enabled)
+        self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
+        self._scale = torch.full((), float(init_scale), dtype=torch.float32, device=device)
+        self._inv = torch.full((1,), 1.0 / float(init_scale), dtype=torch.float32, device=device)
+        self._tracker = torch.zeros((), dtype=torch.int32, device=device)
+        self._overflows = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def get_scale(self):
+        return float(self._scale) if self.enabled else 1.0
+
+    def scale(self, loss):
+        return loss * self._scale if self.enabled else loss
+
+    def step(self, optimizer):
+        """unscale_ + clip_grad_norm_ + optimizer.step(): one pass over the gradients; returns [norm of g / S, clip coefficient]."""
+        if not self.enabled:
+            return optimizer.step()
+        self._norm = optimizer.step(inv_loss_scale=self._inv, overflow_count=self._overflows)
+        return self._norm
+
+    def update(self):
+        if not self.enabled:
+            return
+        found_inf = ~torch.isfinite(self._norm[0])
+        grow = (~found_inf) & (self._tracker + 1 >= self.growth_interval)
+        self._scale = torch.where(found_inf, self._scale * self.backoff_factor, torch.where(grow, self._scale * self.growth_factor, self._scale))
+        self._tracker = torch.where(found_inf | grow, torch.zeros_like(self._tracker), self._tracker + 1)
+        self._inv.copy_((1.0 / self._scale).reshape(1))
+
+
+def train_step(model, optimizer, lr_scheduler, model_func, batch, accumulated_iter, scaler=None):
+    """One iteration of train_one_epoch (train_utils.py:44-64) without logging: returns (loss tensor, tb_dict).
+    scaler: an AmpScaler for the reference's `--use_amp` loop (scale the loss, unscale + clip + step in one pass, update)."""
     lr_scheduler.step(accumulated_iter)
     model.train()
     optimizer.zero_grad()
     loss, tb_dict, disp_dict = model_func(model, batch)
-    loss.backward()
-    optimizer.step()
+    if scaler is not None and scaler.enabled:
+        scaler.scale(loss).backward()
+        scaler.step(optimizer)
+        scaler.update()
+    else:
+        loss.backward()
+        optimizer.step()
     return loss, tb_dict
 
 

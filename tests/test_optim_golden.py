@@ -176,3 +176,53 @@ def test_fused_optimizer_vs_reference_fixture(golden_dir):
         OC.assign_grads(mm, 1)
         o.step()
     assert np.array_equal(_flat(m), _flat(m2))
+
+
+@pytest.mark.gpu
+def test_amp_loss_scaling_matches_torch_gradscaler():
+    """The `--use_amp` control flow (train_utils.py:23,57-64): loss scaling, unscale + clip + step, skipped step on overflow, scale
+    back-off and growth -- AmpScaler + the fused optimizer against torch.cuda.amp.GradScaler driving the same update rule (decoupled
+    decay + torch.optim.Adam, i.e. OptimWrapper.step) on the same gradients."""
+    from radardistill_amd.train import AmpScaler, FusedAdamOneCycle
+    dev = "cuda"
+    g = torch.Generator().manual_seed(0)
+    shapes = [(300,), (64, 3, 3, 32), (4097,)]
+    init = [torch.randn(s, generator=g) for s in shapes]
+    ps = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    rs = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    opt = FusedAdamOneCycle(ps, wd=0.01, grad_clip=10.0)
+    ref = torch.optim.Adam(rs, lr=1e-3, betas=(0.9, 0.99), eps=1e-8)
+    mine = AmpScaler(dev, init_scale=2.0 ** 16, growth_interval=2)
+    theirs = torch.amp.GradScaler("cuda", init_scale=2.0 ** 16, growth_interval=2)
+    lr, mom, wd = 1e-3, 0.9, 0.01
+    for it in range(6):
+        grads = [torch.randn(s, generator=g) * (30.0 if it == 4 else 0.5) for s in shapes]
+        if it == 2:
+            grads[1][0, 0, 0, 0] = float("inf")                       # overflow: both must skip the step and halve the scale
+        theirs.scale(torch.ones((), device=dev))                       # GradScaler creates its device-side state on the first scale()
+        s_mine, s_ref = mine.get_scale(), theirs.get_scale()
+        assert s_mine == s_ref, (it, s_mine, s_ref)
+        for p, r, gg in zip(ps, rs, grads):
+            p.grad = (gg * s_mine).to(dev)
+            r.grad = (gg * s_ref).to(dev)
+        opt.lr, opt.mom = lr, mom
+        norm = mine.step(opt)
+        mine.update()
+        theirs.unscale_(ref)
+        total = torch.nn.utils.clip_grad_norm_(rs, 10.0)
+        for grp in ref.param_groups:
+            grp["lr"], grp["betas"] = lr, (mom, 0.99)
+        before = [r.detach().clone() for r in rs]
+        theirs.step(ref)
+        skipped = all(torch.equal(a, b.detach()) for a, b in zip(before, rs))
+        if not skipped:                                               # OptimWrapper.step: decay happens with the step, not when it is skipped
+            with torch.no_grad():
+                for r, b in zip(rs, before):
+                    r.copy_(b * (1 - wd * lr) + (r - b))
+        theirs.update()
+        assert skipped == (it == 2)
+        if it != 2:
+            np.testing.assert_allclose(float(norm[0]), float(total), rtol=1e-5)
+        for p, r in zip(ps, rs):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), r.detach().cpu().numpy(), rtol=2e-5, atol=1e-6, err_msg=f"step {it}")
+    assert mine.get_scale() == theirs.get_scale()
