@@ -212,21 +212,23 @@ def main():
         D.barrier()
         torch.cuda.synchronize()
 
-    K.prefill_event_pool(min(30000, 900 * (args.steps + 3)))       # timing events created (and their HIP handles) outside the timed region
-    K.CONV_PROFILE = []
-    K.BN_PROFILE = []
+    # Per-launch HIP events (the roofline's kernel durations) bracket ~300 launches of a step and cost ~1 ms of it, so only every
+    # `every`-th step of the timed region carries them (at least 3 steps); the averages are over those steps.
+    every = max(1, min(int(os.environ.get("RD_BENCH_PROFILE_EVERY", "4")), args.steps // 3 or 1))
+    hooked = [it for it in range(args.warmup, args.warmup + args.steps) if (it - args.warmup) % every == 0]
     if os.environ.get("RD_BENCH_NO_HOOKS"):          # diagnostic: cost of the per-launch HIP events themselves
-        K.CONV_PROFILE = K.BN_PROFILE = None
-    K.WGRAD_PROFILE = [] if K.CONV_PROFILE is not None else None
+        hooked = []
+    K.prefill_event_pool(min(30000, 900 * (len(hooked) + 3)))      # timing events created (and their HIP handles) outside the timed region
+    prof, bnprof, wprof = [], [], []
     barrier()
     t0 = time.perf_counter()
     for it in range(args.warmup, args.warmup + args.steps):
+        on = it in hooked
+        K.CONV_PROFILE, K.BN_PROFILE, K.WGRAD_PROFILE = (prof, bnprof, wprof) if on else (None, None, None)
         loss = step(it)
     barrier()
     dt = time.perf_counter() - t0
-    prof, K.CONV_PROFILE = (K.CONV_PROFILE or []), None
-    bnprof, K.BN_PROFILE = (K.BN_PROFILE or []), None
-    wprof, K.WGRAD_PROFILE = K.WGRAD_PROFILE, None
+    K.CONV_PROFILE = K.BN_PROFILE = K.WGRAD_PROFILE = None
     last_loss = float(loss.detach())
     # The timed steps overlap the teacher's kernels (side stream) with the student's, so a launch's event-to-event duration includes
     # time shared with the other stream.  Two extra steps with the overlap switched off give the kernel's isolated duration.
@@ -263,8 +265,9 @@ def main():
         K.set_conv_math(args.math)
         other = {"conv_math": om, "value": round(args.batch * world * args.other_math_steps / odt, 3), "unit": "samples/sec",
                  "ms_per_step": round(odt / args.other_math_steps * 1e3, 3), "steps": args.other_math_steps}
-    roofline_note = "HIP events around every launch of the kernel inside the timed region"
-    prof_steps = args.steps
+    roofline_note = (f"HIP events around every launch of the kernel in {len(hooked)} of the {args.steps} steps of the timed region "
+                     f"(every {every}th step: the events themselves cost ~1 ms per instrumented step)")
+    prof_steps = max(len(hooked), 1)
     dt = D.max_over_ranks(dt, device)
 
     if rank == 0:
