@@ -6,7 +6,7 @@
  *   pcdet/ops/iou3d_nms/src/iou3d_nms_kernel.cu:266-277 (boxes_aligned_overlap_kernel)
  * in single precision, same operation order, EPS 1e-8, MARGIN 1e-2.
  * PARITY UNPINNED by reference tests (none exist); pinned by analytic known answers in
- * tests/test_oracle_iou3d.py.  Built by oracle/Makefile into oracle/_build/liboracle_iou3d.so.
+ * tests/test_oracle_kat.py.  Built by oracle/Makefile into oracle/_build/liboracle_iou3d.so.
  */
 #include <math.h>
 #include <stdlib.h>

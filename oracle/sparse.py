@@ -10,7 +10,7 @@ semantics as used by the reference call sites
   pcdet/models/backbones_3d/spconv_backbone_2d_distillation.py:6-96 (Radar_PillarRes18BackBone8x)
 PARITY UNPINNED against the real spconv binary (no reference tests, library absent).  Pinned here
 by the equivalence "sparse conv on active sites == dense conv on the zero-filled map, sampled at
-the output sites" (tests/test_oracle_sparse.py), which is spconv's defining property.
+the output sites" (tests/test_oracle_kat.py), which is spconv's defining property.
 
 Canonical ordering: spconv's output-row order for SparseConv2d is implementation-defined (GPU hash
 table); the canonical form used for bit-exact index / rulebook parity is rows sorted by (b, y, x).

@@ -6,10 +6,10 @@ import torch
 
 def smoke_check():
     from oracle import sparse as osp, vfe as ovfe          # checker only
-    from .pcdet.config import AttrDict
-    from .pcdet.models.backbones_3d import __all__ as B3
-    from .pcdet.models.backbones_3d.vfe import __all__ as VFE
-    from .synthetic import bench_geometry, make_batch
+    from radardistill_amd.pcdet.config import AttrDict
+    from radardistill_amd.pcdet.models.backbones_3d import __all__ as B3
+    from radardistill_amd.pcdet.models.backbones_3d.vfe import __all__ as VFE
+    from radardistill_amd.synthetic import bench_geometry, make_batch
     dev = "cuda:0"
     grid, B = 128, 2
     pc_range, voxel, gs = bench_geometry(grid)

@@ -39,7 +39,7 @@ def test_package_imports_and_registries():
     import importlib
     for mod in ["radardistill_amd", "radardistill_amd.kernels", "radardistill_amd.autograd", "radardistill_amd.sparse",
                 "radardistill_amd.pcdet", "radardistill_amd.pcdet.config", "radardistill_amd.pcdet.models",
-                "radardistill_amd.pcdet.utils.spconv_utils", "radardistill_amd.selfcheck"]:
+                "radardistill_amd.pcdet.utils.spconv_utils", "radardistill_amd.lowp", "radardistill_amd.graphs", "radardistill_amd.ckpt"]:
         importlib.import_module(mod)
     from radardistill_amd.pcdet.models.backbones_3d import __all__ as B3
     from radardistill_amd.pcdet.models.backbones_3d.vfe import __all__ as VFE
