@@ -476,6 +476,15 @@ int rd_lp_quant_weights(const float *w_k, int Cout, int K, int dtype, void *w_q,
 int rd_lp_conv(const void *in, int dtype, int B, int H, int W, int Cin, int in_ld, const void *w_q, int ksize, int deconv, const float *alpha,
                const float *beta, int relu, void *out, int out_dtype, int Cout, int out_ld, int out_col0, void *stream);
 
+/* ---- R. LayerNorm over the channel axis of channels-last rows (ConvNeXt block, pcdet/ops/basicblock/modules/Basicblock_convn.py:
+ * 58-82: F.layer_norm(x, (C,), weight, bias, 1e-6) on (B, H, W, C)).  Replaces ATen native_layer_norm and its backward kernels.
+ * fwd: y = (x - mean_c) * rstd_c * gamma + beta per row (biased variance), mean / rstd (rows each) kept for bwd.
+ * bwd: grad_x (rows, C); grad_gamma / grad_beta (C each) are zero-filled and accumulated here.  C % 4 == 0, C <= 1024. */
+int rd_layernorm_fwd(const float *x, int64_t rows, int C, const float *gamma, const float *beta, float eps, float *y, float *mean, float *rstd,
+                     void *stream);
+int rd_layernorm_bwd(const float *x, const float *grad_y, int64_t rows, int C, const float *gamma, const float *mean, const float *rstd,
+                     float *grad_x, float *grad_gamma, float *grad_beta, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

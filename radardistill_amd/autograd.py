@@ -873,6 +873,27 @@ def gelu_grn(z_rows, grn, B):
     return _GeluGRNFn.apply(z_rows, grn.gamma, grn.beta, B)
 
 
+class _LayerNormFn(torch.autograd.Function):
+    """LayerNorm over the channels of channels-last rows (layernorm.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        y, stat = K.layernorm_fwd(x, g, b, eps)
+        ctx.save_for_backward(x, g, stat)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, g, stat = ctx.saved_tensors
+        gx, gg, gb = K.layernorm_bwd(x, gy.contiguous(), g, stat)
+        return gx, gg, gb, None
+
+
+def layer_norm_rows(x_rows, weight, bias, eps):
+    return _LayerNormFn.apply(x_rows, weight, bias, float(eps))
+
+
 class _CenterLossFn(torch.autograd.Function):
     """All CenterHead loss terms of all task heads (centerloss.hip): returns (total loss (1,), per-head [hm, loc, iou, iou_reg] (nh, 4))."""
 

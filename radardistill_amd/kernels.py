@@ -768,6 +768,28 @@ def gelu_grn_bwd(grad_out, a, z, ssq, B, gamma):
     return gz, gg, gb
 
 
+# ------------------------------------------------------------------------------------------ LayerNorm over channels-last rows
+def layernorm_fwd(x, gamma, beta, eps):
+    _chk(x, f32, "layernorm input", 2)
+    rows, C = x.shape
+    if _chk(gamma, f32, "gamma").numel() != C or _chk(beta, f32, "beta").numel() != C:
+        raise RuntimeError("layernorm_fwd: gamma / beta must have C elements")
+    y = torch.empty_like(x)
+    stat = torch.empty((2, rows), dtype=f32, device=x.device)
+    check(native.lib().rd_layernorm_fwd(_p(x), rows, C, _p(gamma), _p(beta), float(eps), _p(y), _p(stat[0]), _p(stat[1]), _stream()), "rd_layernorm_fwd")
+    return y, stat
+
+
+def layernorm_bwd(x, grad_y, gamma, stat):
+    _chk(grad_y, f32, "layernorm grad", 2)
+    rows, C = x.shape
+    gx = torch.empty_like(x)
+    g2 = torch.empty(2 * C, dtype=f32, device=x.device)
+    check(native.lib().rd_layernorm_bwd(_p(x), _p(grad_y), rows, C, _p(gamma), _p(stat[0]), _p(stat[1]), _p(gx), _p(g2[:C]), _p(g2[C:]), _stream()),
+          "rd_layernorm_bwd")
+    return gx, g2[:C], g2[C:]
+
+
 # ------------------------------------------------------------------------------------------ padded-voxel input format
 def voxelize_hard(points, batch, grid_xyz, pc_range, voxel_size, max_points, max_voxels):
     """points (N, 1+C) [batch id, x, y, z, ...] sorted by batch id -> (voxels (M, max_points, C), coords (M, 4) int32 (b, z, y, x),

@@ -133,6 +133,8 @@ SIGNATURES = {
     "rd_lp_amax": (c_int, [_P, c_i64, _P, _P]),
     "rd_lp_quant_weights": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     "rd_lp_conv": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    "rd_layernorm_fwd": (c_int, [_P, c_i64, c_int, _P, _P, c_f32, _P, _P, _P, _P]),
+    "rd_layernorm_bwd": (c_int, [_P, _P, c_i64, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "rd_nconv_fwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "rd_nconv_dgrad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
     "rd_nconv_wgrad": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),

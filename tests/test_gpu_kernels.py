@@ -612,3 +612,25 @@ def test_halo_wgrad_3x3_bf16x3(B, H, W, Cin, Cout):
         assert err <= 1e-3 * scale, (name, err, scale)
     assert torch.equal(det, det2)
     print("halo wgrad max err / max", float((got.cpu().double() - ref).abs().max()) / scale)
+
+
+@pytest.mark.parametrize("rows,C", [(8 * 32 * 32, 256), (37, 64), (5, 1024), (1, 256)])
+def test_layernorm_rows_vs_torch(rows, C):
+    """layernorm.hip (one wavefront per channels-last row, shuffle reductions) against F.layer_norm on the CPU: output and the three
+    gradients at the fp32 bound (1e-5 relative: both are fp32, only the summation order differs)."""
+    from radardistill_amd import autograd as A
+    g = np.random.default_rng(rows + C)
+    x = torch.from_numpy(g.normal(1.0, 2.0, size=(rows, C)).astype(np.float32))
+    w = torch.from_numpy(g.uniform(0.5, 1.5, size=C).astype(np.float32))
+    b = torch.from_numpy(g.normal(size=C).astype(np.float32))
+    go = torch.from_numpy(g.normal(size=(rows, C)).astype(np.float32))
+    xr, wr, br = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    ref = F.layer_norm(xr, (C,), wr, br, 1e-6)
+    (ref * go).sum().backward()
+    xd, wd, bd = [t.to(DEV).requires_grad_(True) for t in (x, w, b)]
+    out = A.layer_norm_rows(xd, wd, bd, 1e-6)
+    (out * go.to(DEV)).sum().backward()
+    close(out, ref, rtol=1e-5, atol=1e-5, what="layernorm fwd")
+    close(xd.grad, xr.grad, rtol=1e-4, atol=1e-5, what="layernorm grad x")
+    close(wd.grad, wr.grad, rtol=1e-4, atol=1e-5, what="layernorm grad gamma")
+    close(bd.grad, br.grad, rtol=1e-4, atol=1e-5, what="layernorm grad beta")
