@@ -419,6 +419,16 @@ int rd_pillar_vfe_stats(const float *voxels, const int32_t *num_points, const in
 int rd_pillar_vfe_max(const float *voxels, const int32_t *num_points, const int32_t *coords, int M, int P, int C, const float *weight,
                       int Cin, int Cout, int use_abs_xyz, int with_distance, float vx, float vy, float vz, float xoff, float yoff,
                       float zoff, const float *scale, const float *shift, float *out, void *stream);
+/* General PillarVFE path (training with gradients, several PFN layers, USE_NORM False; pillar_vfe.py:29-49,94-123):
+ * rd_pillar_decorate materialises the masked slot features as rows: out (M*P, ld), columns [0, Cin) as above, [Cin, ld) zero
+ * (ld = Cin rounded up to the implicit GEMM's K step).  Each PFNLayer is then rd_conv_fwd (1 tap) -> rd_bn_* -> rd_pfn_pool_fwd:
+ * x (M*P, C) post-ReLU rows -> last != 0: out (M, C) = max over the P slots; last == 0: out (M*P, 2C) = [x | max repeated]
+ * (torch.cat([x, x_max.repeat(1, P, 1)], dim=2)).  argmax (M, C) int32 = slot of the maximum (first on ties), for the backward:
+ * grad_x (M*P, C) fully written = (last ? 0 : grad_out[:, :C]) + (slot == argmax ? sum over slots of the max's gradient : 0). */
+int rd_pillar_decorate(const float *voxels, const int32_t *num_points, const int32_t *coords, int M, int P, int C, int Cin, int use_abs_xyz,
+                       int with_distance, float vx, float vy, float vz, float xoff, float yoff, float zoff, int ld, float *out, void *stream);
+int rd_pfn_pool_fwd(const float *x, int M, int P, int C, int last, float *out, int32_t *argmax, void *stream);
+int rd_pfn_pool_bwd(const float *grad_out, const int32_t *argmax, int M, int P, int C, int last, float *grad_x, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * O. GELU + Global Response Normalisation of the ConvNeXt-V2 MLP (pcdet/ops/basicblock/modules/Basicblock_convn.py:46-60,83-85):

@@ -53,8 +53,11 @@ def batch_points_to_voxels(points_b, batch, vsize_xyz, range_xyz, max_points, ma
     return np.concatenate(vs), np.concatenate(cs), np.concatenate(ns)
 
 
-def pillar_vfe(voxels, num_points, coords, state, voxel_size, pc_range, use_abs_xyz=True, with_distance=False, training=False, prefix=""):
-    """PillarVFE.forward with one PFNLayer (pillar_vfe.py:85-123, 29-46) -> (M, Cout)."""
+def pillar_vfe(voxels, num_points, coords, state, voxel_size, pc_range, use_abs_xyz=True, with_distance=False, training=False, prefix="",
+               new_running=None):
+    """PillarVFE.forward (pillar_vfe.py:85-123) with its stack of PFNLayers (pillar_vfe.py:29-49: Linear [-> BatchNorm1d over all
+    M*P slots] -> ReLU -> max over the slots; a non-last layer returns [x | max repeated]) -> (M, Cout).  The layer count and
+    USE_NORM are read off the state names; `new_running` (dict) receives the updated running statistics in training mode."""
     vx, vy, vz = voxel_size
     xo, yo, zo = vx / 2 + pc_range[0], vy / 2 + pc_range[1], vz / 2 + pc_range[2]
     mean = voxels[:, :, :3].sum(dim=1, keepdim=True) / num_points.type_as(voxels).view(-1, 1, 1)
@@ -69,12 +72,22 @@ def pillar_vfe(voxels, num_points, coords, state, voxel_size, pc_range, use_abs_
     feats = torch.cat(feats, dim=-1)
     P = feats.shape[1]
     mask = (num_points.int().unsqueeze(1) > torch.arange(P, dtype=torch.int).view(1, -1)).unsqueeze(-1).type_as(voxels)
-    feats = feats * mask
-    x = F.linear(feats, state[prefix + "pfn_layers.0.linear.weight"])
-    p = prefix + "pfn_layers.0.norm."
-    x = F.batch_norm(x.permute(0, 2, 1), state[p + "running_mean"].clone(), state[p + "running_var"].clone(), state[p + "weight"], state[p + "bias"],
-                     training, 0.01, 1e-3).permute(0, 2, 1)
-    return torch.max(F.relu(x), dim=1)[0]
+    x = feats * mask
+    n_layers = 0
+    while f"{prefix}pfn_layers.{n_layers}.linear.weight" in state:
+        n_layers += 1
+    for i in range(n_layers):
+        q = f"{prefix}pfn_layers.{i}."
+        x = F.linear(x, state[q + "linear.weight"], state.get(q + "linear.bias"))
+        if q + "norm.weight" in state:
+            rm, rv = state[q + "norm.running_mean"].clone(), state[q + "norm.running_var"].clone()
+            x = F.batch_norm(x.permute(0, 2, 1), rm, rv, state[q + "norm.weight"], state[q + "norm.bias"], training, 0.01, 1e-3).permute(0, 2, 1)
+            if new_running is not None:
+                new_running[q + "norm.running_mean"], new_running[q + "norm.running_var"] = rm, rv
+        x = F.relu(x)
+        x_max = torch.max(x, dim=1, keepdim=True)[0]
+        x = x_max if i == n_layers - 1 else torch.cat([x, x_max.repeat(1, P, 1)], dim=2)
+    return x.squeeze(1)
 
 
 def scatter(pillar_features, coords, batch, nx, ny):

@@ -187,7 +187,8 @@ struct PvArgs {
 
 __device__ __forceinline__ void pv_stage(const PvArgs &a, int v0, float (*feat)[PV_MAXP][PV_MAX_IN], float (*mean)[4], float *w_l) {
     const int tid = threadIdx.x;
-    for (int i = tid; i < a.Cout * a.Cin; i += 256) w_l[i] = a.w[i];
+    if (w_l)
+        for (int i = tid; i < a.Cout * a.Cin; i += 256) w_l[i] = a.w[i];
     if (tid < PV_VOX * 3) {
         const int vv = tid / 3, k = tid % 3, v = v0 + vv;
         float s = 0.f;
@@ -295,4 +296,92 @@ extern "C" int rd_pillar_vfe_max(const float *voxels, const int32_t *num_points,
     if (M == 0) return RD_OK;
     k_pvfe<1><<<(unsigned)cdiv(M, PV_VOX), 256, 0, S(stream)>>>(a, scale, shift, nullptr, out);
     return check_launch("rd_pillar_vfe_max");
+}
+
+// ---------------------------------------------------------------------------------------------- PillarVFE, general path
+// Training (gradients), several PFN layers, USE_NORM False: the slot features are materialised once as rows (M*P, ld) (zero for
+// padded slots and for the columns >= Cin that pad the row to the implicit-GEMM's K step), every PFNLayer then is Linear (1-tap
+// implicit GEMM) -> BatchNorm over all M*P rows (norm.hip) -> ReLU -> this pooling kernel: max over the P slots of a voxel, and for
+// a non-last layer the concatenation [x | max repeated over the slots] (pillar_vfe.py:40-49).
+__global__ __launch_bounds__(256) void k_pv_decorate(const PvArgs a, int ld, float *__restrict__ out) {
+    __shared__ float feat[PV_VOX][PV_MAXP][PV_MAX_IN];
+    __shared__ float mean[PV_VOX][4];
+    const int v0 = blockIdx.x * PV_VOX;
+    pv_stage(a, v0, feat, mean, nullptr);
+    const int per_vox = a.P * ld;
+    for (int i = threadIdx.x; i < PV_VOX * per_vox; i += 256) {
+        const int vv = i / per_vox, r = i % per_vox, p = r / ld, k = r % ld, v = v0 + vv;
+        if (v < a.M) out[((int64_t)v * a.P + p) * ld + k] = k < a.Cin ? feat[vv][p][k] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pfn_pool_fwd(const float *__restrict__ x, int M, int P, int C, int last, float *__restrict__ out,
+                                                      int32_t *__restrict__ argmax) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)M * C) return;
+    const int m = (int)(idx / C), c = (int)(idx % C);
+    const float *col = x + (int64_t)m * P * C + c;
+    float best = col[0];
+    int bi = 0;
+    for (int p = 1; p < P; ++p) {
+        const float v = col[(int64_t)p * C];
+        if (v > best) {          // first maximum on ties
+            best = v;
+            bi = p;
+        }
+    }
+    if (argmax) argmax[idx] = bi;
+    if (last) {
+        out[idx] = best;
+        return;
+    }
+    float *o = out + (int64_t)m * P * 2 * C + c;
+    for (int p = 0; p < P; ++p) {
+        o[(int64_t)p * 2 * C] = col[(int64_t)p * C];
+        o[(int64_t)p * 2 * C + C] = best;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pfn_pool_bwd(const float *__restrict__ g, const int32_t *__restrict__ argmax, int M, int P, int C, int last,
+                                                      float *__restrict__ gx) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)M * C) return;
+    const int m = (int)(idx / C), c = (int)(idx % C);
+    const int bi = argmax[idx];
+    float *o = gx + (int64_t)m * P * C + c;
+    if (last) {
+        const float gm = g[idx];
+        for (int p = 0; p < P; ++p) o[(int64_t)p * C] = p == bi ? gm : 0.f;
+        return;
+    }
+    const float *gi = g + (int64_t)m * P * 2 * C + c;
+    float gm = 0.f;
+    for (int p = 0; p < P; ++p) gm += gi[(int64_t)p * 2 * C + C];
+    for (int p = 0; p < P; ++p) o[(int64_t)p * C] = gi[(int64_t)p * 2 * C] + (p == bi ? gm : 0.f);
+}
+
+extern "C" int rd_pillar_decorate(const float *voxels, const int32_t *num_points, const int32_t *coords, int M, int P, int C, int Cin,
+                                  int use_abs_xyz, int with_distance, float vx, float vy, float vz, float xoff, float yoff, float zoff, int ld,
+                                  float *out, void *stream) {
+    PvArgs a{voxels, num_points, coords, nullptr, M, P, C, Cin, 1, use_abs_xyz, with_distance, vx, vy, vz, xoff, yoff, zoff};
+    int rc = pv_check(a, "rd_pillar_decorate");
+    if (rc) return rc;
+    RD_REQUIRE(ld >= Cin && out, "rd_pillar_decorate: row stride %d < %d features", ld, Cin);
+    if (M == 0) return RD_OK;
+    k_pv_decorate<<<(unsigned)cdiv(M, PV_VOX), 256, 0, S(stream)>>>(a, ld, out);
+    return check_launch("rd_pillar_decorate");
+}
+
+extern "C" int rd_pfn_pool_fwd(const float *x, int M, int P, int C, int last, float *out, int32_t *argmax, void *stream) {
+    RD_REQUIRE(M >= 0 && P >= 1 && C >= 1 && out, "rd_pfn_pool_fwd: bad sizes");
+    if (M == 0) return RD_OK;
+    k_pfn_pool_fwd<<<(unsigned)cdiv((int64_t)M * C, 256), 256, 0, S(stream)>>>(x, M, P, C, last, out, argmax);
+    return check_launch("rd_pfn_pool_fwd");
+}
+
+extern "C" int rd_pfn_pool_bwd(const float *grad_out, const int32_t *argmax, int M, int P, int C, int last, float *grad_x, void *stream) {
+    RD_REQUIRE(M >= 0 && P >= 1 && C >= 1 && argmax && grad_x, "rd_pfn_pool_bwd: bad sizes");
+    if (M == 0) return RD_OK;
+    k_pfn_pool_bwd<<<(unsigned)cdiv((int64_t)M * C, 256), 256, 0, S(stream)>>>(grad_out, argmax, M, P, C, last, grad_x);
+    return check_launch("rd_pfn_pool_bwd");
 }

@@ -842,6 +842,40 @@ def pillar_vfe_max(voxels, num_points, coords, weight, use_abs, with_dist, geom,
     return out
 
 
+def pillar_decorate(voxels, num_points, coords, Cin, use_abs, with_dist, geom, ld):
+    """-> (M*P, ld) rows: the masked slot features of PillarVFE.forward (pillar_vfe.py:94-118), zero-padded to `ld` columns."""
+    _chk(voxels, f32, "voxels", 3); _chk(num_points, i32, "voxel_num_points", 1); _chk(coords, i32, "voxel_coords", 2)
+    M, P, C = voxels.shape
+    if num_points.shape[0] != M or coords.shape != (M, 4):
+        raise RuntimeError("pillar_decorate: voxel_num_points / voxel_coords do not match voxels")
+    out = torch.empty((M * P, ld), dtype=f32, device=voxels.device)
+    check(native.lib().rd_pillar_decorate(_p(voxels), _p(num_points), _p(coords), M, P, C, int(Cin), int(bool(use_abs)), int(bool(with_dist)),
+                                          *[float(v) for v in geom], int(ld), _p(out), _stream()), "rd_pillar_decorate")
+    return out
+
+
+def pfn_pool_fwd(x, M, P, last):
+    """x (M*P, C) -> (out, argmax): out (M, C) max over the slots (last) or (M*P, 2C) = [x | max repeated] (pillar_vfe.py:42-49)."""
+    _chk(x, f32, "pfn rows", 2)
+    C = x.shape[1]
+    if x.shape[0] != M * P:
+        raise RuntimeError("pfn_pool_fwd: rows != M*P")
+    out = torch.empty((M, C) if last else (M * P, 2 * C), dtype=f32, device=x.device)
+    argmax = torch.empty((M, C), dtype=i32, device=x.device)
+    check(native.lib().rd_pfn_pool_fwd(_p(x), M, P, C, int(bool(last)), _p(out), _p(argmax), _stream()), "rd_pfn_pool_fwd")
+    return out, argmax
+
+
+def pfn_pool_bwd(grad_out, argmax, M, P, last):
+    _chk(grad_out, f32, "grad_out", 2); _chk(argmax, i32, "argmax", 2)
+    C = argmax.shape[1]
+    if tuple(grad_out.shape) != ((M, C) if last else (M * P, 2 * C)):
+        raise RuntimeError("pfn_pool_bwd: grad_out shape does not match the forward output")
+    gx = torch.empty((M * P, C), dtype=f32, device=grad_out.device)
+    check(native.lib().rd_pfn_pool_bwd(_p(grad_out), _p(argmax), M, P, C, int(bool(last)), _p(gx), _stream()), "rd_pfn_pool_bwd")
+    return gx
+
+
 # ------------------------------------------------------------------------------------------ inference post-processing
 def nms_bev(boxes_sorted, thresh):
     """boxes (n, 7) sorted by descending score -> (keep (n,) int64 device, num_keep 0-d int32 device): rotated-BEV greedy NMS,

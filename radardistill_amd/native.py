@@ -123,6 +123,9 @@ SIGNATURES = {
                                     _P, _P]),
     "rd_pillar_vfe_max": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32,
                                   _P, _P, _P, _P]),
+    "rd_pillar_decorate": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, _P, _P]),
+    "rd_pfn_pool_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "rd_pfn_pool_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "rd_gelu_grn_fwd": (c_int, [_P, c_int, c_i64, c_int, _P, _P, _P, _P, _P, _P]),
     "rd_gelu_grn_bwd": (c_int, [_P, _P, _P, _P, c_int, c_i64, c_int, _P, _P, _P, _P, _P, _P]),
     "rd_nms_ws_bytes": (c_i64, [c_int]),

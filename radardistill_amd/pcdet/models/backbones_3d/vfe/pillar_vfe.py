@@ -1,11 +1,39 @@
 """PillarVFE over the padded-voxel input format (pcdet/models/backbones_3d/vfe/pillar_vfe.py:8-123) on the HIP kernels of
 hardvox.hip.  Module tree and state_dict names are the reference's (`pfn_layers.0.linear.weight`, `pfn_layers.0.norm.*`).
-Inference / no-grad forward only: the RadarDistill training configs use the dynamic VFE; one PFN layer."""
+
+Two paths, same results:
+  * no gradients, one PFN layer with BatchNorm (inference / frozen use): feature assembly + Linear + BN + ReLU + slot max fused in
+    ONE kernel (two passes in train mode for the batch statistics) -- rd_pillar_vfe_{stats,max};
+  * everything else (training with gradients, several PFN layers, USE_NORM False): rd_pillar_decorate writes the masked slot
+    features as rows once, each PFNLayer is the 1-tap implicit GEMM -> BatchNorm rows kernel -> rd_pfn_pool (slot max, and for a
+    non-last layer the [x | max] concatenation), every piece an autograd node with a HIP backward.
+"""
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
+from radardistill_amd import autograd as A
 from radardistill_amd import kernels as K
 from .vfe_template import VFETemplate
+
+
+def _pad32(n):
+    return (n + 31) // 32 * 32
+
+
+class _PfnPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, M, P, last):
+        out, argmax = K.pfn_pool_fwd(x.contiguous(), M, P, last)
+        ctx.save_for_backward(argmax)
+        ctx.dims = (M, P, last)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (argmax,) = ctx.saved_tensors
+        M, P, last = ctx.dims
+        return K.pfn_pool_bwd(g.contiguous(), argmax, M, P, last), None, None, None
 
 
 class PFNLayer(nn.Module):
@@ -22,7 +50,48 @@ class PFNLayer(nn.Module):
             self.norm = nn.BatchNorm1d(out_channels, eps=1e-3, momentum=0.01)
         else:
             self.linear = nn.Linear(in_channels, out_channels, bias=True)
-        self.part = 50000
+        self.part = 50000          # the reference splits its nn.Linear call above this many rows (pillar_vfe.py:30-36); one launch here
+        self.out_channels = out_channels
+
+    def forward_rows(self, x, M, P, cols=None):
+        """x (M*P, ld) rows whose logical input columns sit at `cols` (None: the first in_features columns; the rest are zero) ->
+        last layer: (M, Cp); else (M*P, 2*Cp) = [x | max], Cp = out_channels rounded up to 32 (padded channels are exact zeros)."""
+        Cout, Cin, ld = self.out_channels, self.linear.in_features, x.shape[1]
+        Cp = _pad32(Cout)
+        w = self.linear.weight
+        if Cp != Cout:
+            w = F.pad(w, (0, 0, 0, Cp - Cout))
+        if cols is not None:
+            w = w.new_zeros((Cp, ld)).index_copy(1, cols, w)
+        elif ld != Cin:
+            w = F.pad(w, (0, ld - Cin))
+        b = self.linear.bias
+        if b is not None and Cp != Cout:
+            b = F.pad(b, (0, Cp - Cout))
+        rows = M * P
+        if self.use_norm:
+            bn = self.norm
+            if bn.training:
+                if rows <= 1:
+                    raise ValueError("Expected more than 1 value per channel when training")
+                x = A.conv(x, w, b, A.linear_spec(rows), Cp, None)
+                if Cp == Cout:
+                    x = A.bn_act_train(x, bn, act=1)
+                else:       # padded channels: gamma 1, beta 0, throw-away running statistics
+                    rm, rv = F.pad(bn.running_mean, (0, Cp - Cout)), F.pad(bn.running_var, (0, Cp - Cout), value=1.0)
+                    x = A.bn_act_train_tensors(x, F.pad(bn.weight, (0, Cp - Cout), value=1.0), F.pad(bn.bias, (0, Cp - Cout)), rm, rv,
+                                               float(bn.eps), float(bn.momentum), act=1, modules=(bn,))
+                    with torch.no_grad():
+                        bn.running_mean.copy_(rm[:Cout]); bn.running_var.copy_(rv[:Cout])
+            else:
+                x = A.conv(x, w, b, A.linear_spec(rows), Cp, None)
+                scale, shift = A.bn_eval_scale_shift(bn)
+                if Cp != Cout:
+                    scale, shift = F.pad(scale, (0, Cp - Cout)), F.pad(shift, (0, Cp - Cout))
+                x = A._BNEvalActFn.apply(x, scale.contiguous(), shift.contiguous(), None, 1)
+        else:
+            x = torch.relu(A.conv(x, w, b, A.linear_spec(rows), Cp, None))
+        return _PfnPoolFn.apply(x, M, P, self.last_vfe)
 
 
 class PillarVFE(VFETemplate):
@@ -49,17 +118,30 @@ class PillarVFE(VFETemplate):
         return self.num_filters[-1]
 
     def forward(self, batch_dict, **kwargs):
-        if len(self.pfn_layers) != 1 or not self.use_norm:
-            raise NotImplementedError("PillarVFE on MI355X: one PFN layer with BatchNorm (NUM_FILTERS: [64], USE_NORM: True)")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("PillarVFE backward is not built: the RadarDistill training path uses the dynamic VFE "
-                                      "(run under torch.no_grad() or freeze the module)")
         voxels = batch_dict['voxels'].float().contiguous()
         num = batch_dict['voxel_num_points'].int().contiguous()
         coords = batch_dict['voxel_coords'].int().contiguous()
+        geom = (self.voxel_x, self.voxel_y, self.voxel_z, self.x_offset, self.y_offset, self.z_offset)
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if len(self.pfn_layers) == 1 and self.use_norm and not needs_grad and self.num_filters[0] <= 64:
+            batch_dict['pillar_features'] = self._forward_fused(voxels, num, coords, geom)
+            return batch_dict
+        M, P = voxels.shape[0], voxels.shape[1]
+        Cin = self.pfn_layers[0].linear.in_features
+        x = K.pillar_decorate(voxels, num, coords, Cin, self.use_absolute_xyz, self.with_distance, geom, _pad32(Cin))
+        cols = None
+        for pfn in self.pfn_layers:
+            x = pfn.forward_rows(x, M, P, cols)
+            C, Cp = pfn.out_channels, _pad32(pfn.out_channels)
+            # the next layer reads [x | max]: logical column c of either half sits at c / Cp + c of the padded concatenation
+            cols = None if C == Cp else torch.cat([torch.arange(C, device=x.device), Cp + torch.arange(C, device=x.device)])
+        C = self.pfn_layers[-1].out_channels
+        batch_dict['pillar_features'] = x if x.shape[1] == C else x[:, :C]        # (M, Cout); the reference's .squeeze() of (M, 1, Cout)
+        return batch_dict
+
+    def _forward_fused(self, voxels, num, coords, geom):
         pfn = self.pfn_layers[0]
         w = pfn.linear.weight.detach().contiguous()
-        geom = (self.voxel_x, self.voxel_y, self.voxel_z, self.x_offset, self.y_offset, self.z_offset)
         bn = pfn.norm
         with torch.no_grad():
             if bn.training:
@@ -78,6 +160,4 @@ class PillarVFE(VFETemplate):
                 rstd = torch.rsqrt(bn.running_var + bn.eps)
                 scale = (bn.weight * rstd).contiguous()
                 shift = (bn.bias - bn.running_mean * scale).contiguous()
-            feats = K.pillar_vfe_max(voxels, num, coords, w, self.use_absolute_xyz, self.with_distance, geom, scale.contiguous(), shift.contiguous())
-        batch_dict['pillar_features'] = feats        # (M, Cout); the reference's .squeeze() of (M, 1, Cout)
-        return batch_dict
+            return K.pillar_vfe_max(voxels, num, coords, w, self.use_absolute_xyz, self.with_distance, geom, scale.contiguous(), shift.contiguous())

@@ -275,6 +275,44 @@ def g7_pillar():
     save("g7_pillar.npz", **out)
 
 
+G9_CASES = (("a", True, False, True, [64]), ("c", True, False, True, [64, 64]), ("d", False, True, True, [32, 128]), ("e", True, False, False, [64]))
+
+
+def g9_pillar_train():
+    """PillarVFE of the reference in TRAINING use: forward + parameter gradients of loss = sum(features * go) for one PFN layer, two
+    layers (the [x | max] concatenation), a 16-channel first layer and USE_NORM False (pillar_vfe.py:8-49,94-123)."""
+    from oracle import voxel as ovox
+    pv = L.load("pcdet.models.backbones_3d.vfe.pillar_vfe")
+    pc_range, voxel, grid = bench_geometry(128)
+    voxel = [voxel[0], voxel[1], pc_range[5] - pc_range[2]]
+    batch = make_batch(batch_size=2, n_lidar=1500, n_radar=16, n_boxes=2, grid=128, seed=8)
+    vox, coords, num = ovox.batch_points_to_voxels(batch["points"], 2, voxel, pc_range, max_points=8, max_voxels=700)
+    out = {}
+    torch.set_grad_enabled(True)
+    for tag, use_abs, with_dist, use_norm, filters in G9_CASES:
+        cfg = L.AttrDict(USE_NORM=use_norm, WITH_DISTANCE=with_dist, USE_ABSLOTE_XYZ=use_abs, NUM_FILTERS=filters)
+        m = pv.PillarVFE(cfg, num_point_features=5, voxel_size=voxel, point_cloud_range=pc_range)
+        sd = m.state_dict(); seeded_fill_(sd, seed=41); m.load_state_dict(sd)
+        m.train()
+        bd = m({"voxels": torch.from_numpy(vox), "voxel_num_points": torch.from_numpy(num), "voxel_coords": torch.from_numpy(coords)})
+        feats = bd["pillar_features"]
+        go = torch.from_numpy(np.random.default_rng(9).normal(size=tuple(feats.shape)).astype(np.float32))
+        (feats * go).sum().backward()
+        out[f"{tag}_features"] = feats.detach()             # `go` is regenerated by the tests from the same seed
+        for k, p in m.named_parameters():
+            out[f"{tag}_grad_{k}"] = p.grad.detach()
+        for k, b in m.named_buffers():
+            if "running" in k:
+                out[f"{tag}_{k}"] = b.detach().clone()
+        m.eval()
+        with torch.no_grad():
+            bd = m({"voxels": torch.from_numpy(vox), "voxel_num_points": torch.from_numpy(num), "voxel_coords": torch.from_numpy(coords)})
+        out[f"{tag}_eval_features"] = bd["pillar_features"]
+        print(tag, "features", tuple(feats.shape), "params", [k for k, _ in m.named_parameters()])
+    torch.set_grad_enabled(False)
+    save("g9_pillar_train.npz", **out)
+
+
 def g8_optim():
     """A13: the reference's own build_optimizer / OptimWrapper / OneCycle + clip_grad_norm_ loop (tools/train_utils/optimization/
     __init__.py:19-54, fastai_optim.py:104-235, learning_schedules_fastai.py:44-77, train_utils.py:44-64) on the small problem
@@ -331,9 +369,9 @@ def _fresh_reference_modules():
 
 if __name__ == "__main__":
     torch.set_grad_enabled(False)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     fns = {"g1": g1_vfe, "g2": g2_dense_enc, "g3": g3_radar_distill, "g4": g4_center_head, "g5": g5_conv5, "g6": g6_decode, "g7": g7_pillar,
-           "g8": g8_optim}
+           "g8": g8_optim, "g9": g9_pillar_train}
     for w in which:
         _fresh_reference_modules()
         torch.set_grad_enabled(False)

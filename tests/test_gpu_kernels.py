@@ -534,8 +534,50 @@ def test_pillar_vfe_and_scatter_golden(golden_dir):
                 bd = s(m({"voxels": v, "voxel_num_points": n, "voxel_coords": c, "batch_size": 2}))
             assert bd["spatial_features"].shape == (2, 64, 128, 128)
             close(bd["spatial_features"], g["spatial_features"], what="scatter")
-    with pytest.raises(NotImplementedError):
-        m.train(); m({"voxels": v, "voxel_num_points": n, "voxel_coords": c})     # gradients requested: not built
+
+
+@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+def test_pillar_vfe_training_and_multi_layer_golden(golden_dir, math):
+    """PillarVFE in training use (pillar_vfe.py:8-49,94-123) on HIP: rd_pillar_decorate -> per PFN layer [1-tap implicit GEMM ->
+    BatchNorm rows -> rd_pfn_pool] with HIP backward, vs the reference module's own outputs AND parameter gradients (fixture g9:
+    one layer, two layers with the [x | max] concatenation, a 16-channel first layer, USE_NORM False)."""
+    A, K, SP = _mods()
+    from radardistill_amd.pcdet.config import AttrDict
+    from radardistill_amd.pcdet.models.backbones_3d.vfe import __all__ as VFE
+    from radardistill_amd.voxel import VoxelGenerator
+    from tests.test_oracle_golden import G9_CASES
+    g = np.load(f"{golden_dir}/g9_pillar_train.npz")
+    pc_range, voxel, grid = bench_geometry(128)
+    voxel = [voxel[0], voxel[1], pc_range[5] - pc_range[2]]
+    batch = make_batch(batch_size=2, n_lidar=1500, n_radar=16, n_boxes=2, grid=128, seed=8)
+    v, c, n = VoxelGenerator(voxel, pc_range, 5, 8, 700).generate(torch.from_numpy(batch["points"]).to(DEV), batch_size=2)
+    K.set_conv_math(math)
+    try:
+        for tag, use_abs, with_dist, use_norm, filters in G9_CASES:
+            m = VFE["PillarVFE"](AttrDict(USE_NORM=use_norm, WITH_DISTANCE=with_dist, USE_ABSLOTE_XYZ=use_abs, NUM_FILTERS=filters),
+                                 num_point_features=5, voxel_size=voxel, point_cloud_range=pc_range)
+            sd = m.state_dict(); seeded_fill_(sd, seed=41); m.load_state_dict(sd); m = m.to(DEV)
+            m.train()
+            A.begin_step(torch.device(DEV))
+            feats = m({"voxels": v, "voxel_num_points": n, "voxel_coords": c, "batch_size": 2})["pillar_features"]
+            A.end_forward()
+            go = torch.from_numpy(np.random.default_rng(9).normal(size=tuple(feats.shape)).astype(np.float32)).to(DEV)
+            (feats * go).sum().backward()
+            close(feats, g[f"{tag}_features"], what=f"{tag} train features")
+            for k, p in m.named_parameters():
+                ref = g[f"{tag}_grad_{k}"]
+                close(p.grad, ref, rtol=2e-3, atol=2e-5 * float(np.abs(ref).max()) + 1e-6, what=f"{tag} grad {k}")
+            for k, b in m.named_buffers():
+                if "running" in k:
+                    close(b, g[f"{tag}_{k}"], what=f"{tag} {k}")
+                elif k.endswith("num_batches_tracked"):
+                    assert int(b) == 1
+            m.eval()
+            with torch.no_grad():
+                ev = m({"voxels": v, "voxel_num_points": n, "voxel_coords": c, "batch_size": 2})["pillar_features"]
+            close(ev, g[f"{tag}_eval_features"], what=f"{tag} eval features")
+    finally:
+        K.set_conv_math("bf16x3")
 
 
 def test_full_size_voxelizer_and_rulebook_pyramid_bit_exact():

@@ -242,3 +242,51 @@ def test_g7_pillar_vfe_and_scatter(golden_dir):
     st["pfn_layers.0.norm.running_mean"] = torch.from_numpy(g["a_running_mean"]); st["pfn_layers.0.norm.running_var"] = torch.from_numpy(g["a_running_var"])
     feats = ovox.pillar_vfe(v, n, c, st, voxel, pc_range, True, False, training=False)
     _close(ovox.scatter(feats, c, 2, int(grid[0]), int(grid[1])), g["spatial_features"], rtol=1e-4, atol=1e-5)
+
+
+G9_CASES = (("a", True, False, True, [64]), ("c", True, False, True, [64, 64]), ("d", False, True, True, [32, 128]), ("e", True, False, False, [64]))
+
+
+def g9_state(cin, use_norm, filters, seed=41):
+    """state_dict of a PillarVFE with these NUM_FILTERS (pillar_vfe.py:8-27,70-79), seeded by name like the generator's module."""
+    dims = [cin] + list(filters)
+    sd = {}
+    for i in range(len(filters)):
+        co = dims[i + 1] if i == len(filters) - 1 else dims[i + 1] // 2
+        ci = dims[i] if i == 0 else 2 * prev
+        q = f"pfn_layers.{i}."
+        sd[q + "linear.weight"] = torch.zeros(co, ci)
+        if use_norm:
+            sd.update({q + "norm.weight": torch.zeros(co), q + "norm.bias": torch.zeros(co), q + "norm.running_mean": torch.zeros(co),
+                       q + "norm.running_var": torch.ones(co), q + "norm.num_batches_tracked": torch.zeros((), dtype=torch.long)})
+        else:
+            sd[q + "linear.bias"] = torch.zeros(co)
+        prev = co
+    return seeded_fill_(sd, seed=seed)
+
+
+def test_g9_pillar_vfe_training_and_multi_layer(golden_dir):
+    """oracle.voxel.pillar_vfe with 1 / 2 PFN layers, a 16-channel first layer and USE_NORM False: training-mode features, the
+    gradients of every parameter under loss = sum(features * go), running statistics and eval-mode features, against the reference
+    module (fixture g9)."""
+    from oracle import voxel as ovox
+    g = np.load(f"{golden_dir}/g9_pillar_train.npz")
+    batch, pc_range, voxel, grid, vox, coords, num = _g7_inputs()
+    v, n, c = torch.from_numpy(vox), torch.from_numpy(num), torch.from_numpy(coords)
+    for tag, use_abs, with_dist, use_norm, filters in G9_CASES:
+        cin = (5 if use_abs else 2) + 6 + (1 if with_dist else 0)
+        st = g9_state(cin, use_norm, filters)
+        params = {k: t.clone().requires_grad_(True) for k, t in st.items() if torch.is_floating_point(t) and "running" not in k}
+        run = {}
+        with torch.enable_grad():
+            feats = ovox.pillar_vfe(v, n, c, {**st, **params}, voxel, pc_range, use_abs, with_dist, training=True, new_running=run)
+            go = torch.from_numpy(np.random.default_rng(9).normal(size=tuple(feats.shape)).astype(np.float32))
+            (feats * go).sum().backward()
+        _close(feats.detach(), g[f"{tag}_features"], rtol=1e-4, atol=1e-5)
+        for k, p in params.items():
+            ref = g[f"{tag}_grad_{k}"]
+            _close(p.grad, ref, rtol=1e-3, atol=1e-5 * float(np.abs(ref).max()) + 1e-7)
+        for k, t in run.items():
+            _close(t, g[f"{tag}_{k}"], rtol=1e-5, atol=1e-6)
+        ev = ovox.pillar_vfe(v, n, c, {**st, **run}, voxel, pc_range, use_abs, with_dist, training=False)
+        _close(ev, g[f"{tag}_eval_features"], rtol=1e-4, atol=1e-5)
