@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="samples per GPU (BATCH_SIZE_PER_GPU of the reference yaml)")
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-bn", action="store_true", help="the reference's --sync_bn (tools/train.py:34,144-145): synchronised BatchNorm "
+                    "statistics over the ranks (off in the headline, as in the reference's default)")
     ap.add_argument("--math", choices=["f32", "bf16x3"], default="bf16x3",
                     help="arithmetic of the implicit-GEMM conv kernels: bf16x3 = fp32 operands split into bf16 hi+lo, three bf16 MFMAs per "
                          "product, fp32 accumulate (~4e-6 relative error, inside the 1e-3 parity bound; parity-tested in "
@@ -173,6 +175,9 @@ def main():
 
     K.set_conv_math(args.math)
     model, cfg, geom = build(os.path.join(ROOT, "tools/cfgs/radar_distill/bench_512.yaml"), args.grid, device)
+    if args.sync_bn:
+        from radardistill_amd.train import convert_sync_batchnorm
+        model = convert_sync_batchnorm(model)
     model.train()
     optimizer = build_optimizer(model, cfg.OPTIMIZATION)
     total_steps = args.steps + args.warmup
@@ -350,7 +355,7 @@ def main():
             "config": {"workload": "RadarDistill full training step (BASELINE configs[3]): frozen LiDAR teacher fwd + radar student "
                                    "fwd/bwd (VFE, SparseEnc, CMA+DCNv2, DenseEnc, CenterHead, AFD+PFD+detection losses) + clip + Adam",
                        "bev": f"{args.grid}x{args.grid}", "pillar_m": 0.2, "lidar_pts": 35000, "radar_pts": 2000, "boxes": 30,
-                       "conv_math": args.math, "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}" + ("" if world == 1 else ("/ddp" if os.environ.get("RD_DDP", "flat") == "torch" else "/flat-allreduce")),
+                       "conv_math": args.math, "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}" + ("" if world == 1 else ("/ddp" if os.environ.get("RD_DDP", "flat") == "torch" else "/flat-allreduce")) + ("+sync_bn" if args.sync_bn else ""),
                        "teacher_head": "computed (unused by the loss, as in the reference)", "final_loss": last_loss},
             "roofline": {"bound": "mfma", "kernel": kname + "; " + arith,
                          "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",

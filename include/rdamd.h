@@ -107,6 +107,17 @@ int rd_vfe_backward(const float *points, int n_points, int n_feat, const int32_t
                     const float *mean, const float *rstd, const float *gamma, const float *beta,
                     const float *grad_out, const int32_t *argmax, int n_pillars, int n_valid,
                     float *grad_weight, float *grad_gamma, float *grad_beta, float *ws, void *stream);
+/* The same in two halves for SyncBatchNorm (see section D): _reduce scatters grad_out to the arg-max points (kept in ws) and
+ * accumulates this rank's (grad_gamma, grad_beta); the host all-reduces a copy over its process group; _weight takes the group-wide
+ * sums and count_dev[0] = group-wide number of in-range points. */
+int rd_vfe_backward_reduce(const float *points, int n_points, int n_feat, const int32_t *point_row, const int32_t *coords,
+                           const float *pillar_acc, const float *weight, const float *geom, const float *mean, const float *rstd,
+                           const float *gamma, const float *beta, const float *grad_out, const int32_t *argmax, int n_pillars,
+                           float *grad_gamma, float *grad_beta, float *ws, void *stream);
+int rd_vfe_backward_weight(const float *points, int n_points, int n_feat, const int32_t *point_row, const int32_t *coords,
+                           const float *pillar_acc, const float *weight, const float *geom, const float *mean, const float *rstd,
+                           const float *gamma, const float *sum_gamma, const float *sum_beta, const float *count_dev, int n_pillars,
+                           float *grad_weight, const float *ws, void *stream);
 
 /* Segmented form of the VFE (vfe_seg.hip; the default path): rd_vfe_group groups the in-range points by pillar (integer counting sort on
  * point_row: offsets (n_pillars + 1), order (point indices, n_valid of them used); ws: rd_vfe_group_ws_bytes(n_pillars) bytes), then
@@ -237,6 +248,24 @@ int rd_affine_act(const float *x, int64_t rows, int C, const float *scale, const
 int rd_bn_bwd(const float *x, const float *y, const float *grad_y, int64_t rows, int C, const float *gamma,
               const float *mean, const float *rstd, const float *scale, const float *shift, int act, int has_residual,
               float *grad_x, float *grad_res, float *grad_gamma, float *grad_beta, void *stream);
+/* SyncBatchNorm (tools/train.py:34,144-145: --sync_bn -> torch.nn.SyncBatchNorm.convert_sync_batchnorm).  The library never
+ * communicates; the host all-reduces two small buffers per layer over its process group and these entries take the group-wide
+ * values from DEVICE memory (no host round trip per layer):
+ *   forward : stats[2C + 1] = (sum, sum of squares, row count) summed over the group -> rd_bn_train_fwd_sync / rd_bn_finalize_sync
+ *             (`rows` = this rank's rows; mean / variance / running statistics use the group-wide count stats[2C]);
+ *   backward: rd_bn_bwd_reduce accumulates THIS rank's (grad_gamma, grad_beta) (zero-filled by the caller) -- these are the
+ *             parameter gradients, as torch's SyncBatchNorm returns them; the host all-reduces a copy; rd_bn_bwd_apply computes
+ *             grad_x (and grad_res) from the group-wide sums and count_dev[0] = group-wide row count. */
+int rd_bn_train_fwd_sync(const float *x, int64_t rows, int C, const float *stats /*[2C+1]*/, const float *gamma, const float *beta, float eps,
+                         float momentum, float *running_mean, float *running_var, const float *residual, int act, float *y,
+                         float *mean, float *rstd, float *scale, float *shift, void *stream);
+int rd_bn_finalize_sync(const float *stats /*[2C+1]*/, int C, const float *gamma, const float *beta, float eps, float momentum,
+                        float *running_mean, float *running_var, float *mean, float *rstd, float *scale, float *shift, void *stream);
+int rd_bn_bwd_reduce(const float *x, const float *y, const float *grad_y, int64_t rows, int C, const float *mean, const float *rstd,
+                     const float *scale, const float *shift, int act, int has_residual, float *grad_gamma, float *grad_beta, void *stream);
+int rd_bn_bwd_apply(const float *x, const float *y, const float *grad_y, int64_t rows, int C, const float *gamma, const float *mean,
+                    const float *rstd, const float *scale, const float *shift, int act, int has_residual, const float *sum_gamma,
+                    const float *sum_beta, const float *count_dev, float *grad_x, float *grad_res, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * E. Sparse -> dense BEV (SparseConvTensor.dense(), spconv_backbone_2d.py:299) in channels-last, and back.

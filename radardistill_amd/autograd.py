@@ -624,83 +624,134 @@ def conv_inference(x, weight, bias, spec, Cout, scale=None, shift=None, residual
                       relu=relu, nbr_keepalive=spec.fwd_nbr)
 
 
+SYNC_BN = [False]          # train.convert_sync_batchnorm(model): every train-mode BatchNorm reduces its batch statistics over the group
+
+
+def sync_group(bn=None):
+    """Process group a train-mode BatchNorm synchronises over, or None: torch.nn.SyncBatchNorm modules (the reference's --sync_bn,
+    tools/train.py:144-145) and/or the global switch, and only when a process group with more than one rank exists."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    if isinstance(bn, torch.nn.SyncBatchNorm):
+        group = bn.process_group if bn.process_group is not None else dist.group.WORLD
+    elif SYNC_BN[0]:
+        group = dist.group.WORLD
+    else:
+        return None
+    return group if dist.get_world_size(group) > 1 else None
+
+
+def _group_sum(group):
+    import torch.distributed as dist
+    return lambda t: dist.all_reduce(t, group=group)
+
+
+def synced_stats(stats_ext, C, rows, group):
+    """stats_ext (2C + 1): local (sum, sumsq) already in [0, 2C) -> row count appended, summed over the group in place."""
+    stats_ext[2 * C:].fill_(float(rows))
+    _group_sum(group)(stats_ext)
+    return stats_ext
+
+
 class _BNActFn(torch.autograd.Function):
     """y = act(batchnorm_train(x) [+ residual]) over rows; batch statistics either precomputed by the producing conv
-    kernel's epilogue (`stats`) or computed here."""
+    kernel's epilogue (`stats`) or computed here.  group: SyncBatchNorm process group (stats then has room for 2C + 1 values)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, act, stats):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, act, stats, group=None):
         rows, C = x.shape
-        if stats is None:
+        if group is not None:
+            if stats is None:
+                stats = K.bn_stats(x, extra=1)
+            stats = synced_stats(stats, C, rows, group)
+        elif stats is None:
             stats = K.bn_stats(x)
-        y, mean, rstd, scale, shift = K.bn_train_fwd(x, stats, gamma, beta, eps, momentum, running_mean, running_var, residual, act)
-        ctx.act, ctx.has_res = act, residual is not None
+        y, mean, rstd, scale, shift = K.bn_train_fwd(x, stats, gamma, beta, eps, momentum, running_mean, running_var, residual, act,
+                                                     sync=group is not None)
+        ctx.act, ctx.has_res, ctx.group = act, residual is not None, group
+        ctx.count = stats[2 * C:] if group is not None else None          # a slice of the per-step arena (shared version counter): kept as an attribute
         ctx.save_for_backward(x, y, gamma, mean, rstd, scale, shift)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, y, gamma, mean, rstd, scale, shift = ctx.saved_tensors
-        gx, gres, gg, gb = K.bn_bwd(x, y, gy.contiguous(), gamma, mean, rstd, scale, shift, ctx.act, ctx.has_res)
-        if _DEBUG and ctx.act in (0, 1):
+        sync = (_group_sum(ctx.group), ctx.count) if ctx.group is not None else None
+        gx, gres, gg, gb = K.bn_bwd(x, y, gy.contiguous(), gamma, mean, rstd, scale, shift, ctx.act, ctx.has_res, sync=sync)
+        if _DEBUG and ctx.act in (0, 1) and sync is None:
             g = gy.double() * ((y > 0).double() if ctx.act == 1 else 1.0)
             xh = (x.double() - mean.double()) * rstd.double()
             n = x.shape[0]
             ref = gamma.double() * rstd.double() * (g - g.sum(0) / n - xh * (g * xh).sum(0) / n)
             _dbg_report(f"bn bwd C={x.shape[1]} rows={n} res={ctx.has_res}", gx.double(), ref)
             if ctx.has_res:
-                _dbg_report("bn bwd residual grad", gres.double(), g)
-        return gx, gg, gb, gres, None, None, None, None, None, None
+                _dbg_report("bn bwd residual grad", gx.double() * 0 + gres.double(), g)
+        return gx, gg, gb, gres, None, None, None, None, None, None, None
 
 
 def bn_act_train(x, bn, residual=None, act=1, stats=None):
     """bn: nn.BatchNorm1d/2d module (train mode semantics: batch stats, running-stat update)."""
-    if x.shape[0] <= 1:
+    group = sync_group(bn)
+    if x.shape[0] <= 1 and group is None:
         raise ValueError("Expected more than 1 value per channel when training")     # torch's own train-mode BN error
     _BN_TOUCHED.append(bn)
-    return _BNActFn.apply(x, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, float(bn.eps), float(bn.momentum), act, stats)
+    if group is not None and stats is not None and stats.numel() != 2 * x.shape[1] + 1:
+        stats = torch.cat([stats, stats.new_zeros(1)])
+    return _BNActFn.apply(x, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, float(bn.eps), float(bn.momentum), act, stats, group)
 
 
 def bn_act_train_tensors(x, gamma, beta, running_mean, running_var, eps, momentum, act=1, stats=None, modules=()):
     """Train-mode BatchNorm over explicit tensors (several BatchNorm modules batched on the channel axis); `modules` get their
     num_batches_tracked bumped with everything else at end_forward()."""
-    if x.shape[0] <= 1:
+    group = sync_group(modules[0] if modules else None)
+    if x.shape[0] <= 1 and group is None:
         raise ValueError("Expected more than 1 value per channel when training")
     _BN_TOUCHED.extend(modules)
-    return _BNActFn.apply(x, gamma, beta, None, running_mean, running_var, eps, momentum, act, stats)
+    if group is not None and stats is not None and stats.numel() != 2 * x.shape[1] + 1:
+        stats = torch.cat([stats, stats.new_zeros(1)])
+    return _BNActFn.apply(x, gamma, beta, None, running_mean, running_var, eps, momentum, act, stats, group)
 
 
 class _ConvBNActFn(torch.autograd.Function):
     """conv (+bias) -> train-mode BatchNorm (statistics from the conv epilogue) -> (+residual) -> activation as ONE autograd node:
     the same four launches as _ConvFn + _BNActFn (forward: conv, BN apply; backward: BN reduce + apply, data gradient, weight
-    gradient), but one Function.apply and one backward node per layer instead of two (~20 us of host time per layer and step)."""
+    gradient), but one Function.apply and one backward node per layer instead of two (~20 us of host time per layer and step).
+    group: SyncBatchNorm process group (one small all-reduce in the forward, one in the backward)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, spec, Cout, gamma, beta, residual, running_mean, running_var, eps, momentum, act):
-        stats = zeros_stats(2 * Cout, x.device)
+    def forward(ctx, x, weight, bias, spec, Cout, gamma, beta, residual, running_mean, running_var, eps, momentum, act, group=None):
+        sync = group is not None
+        ext = zeros_stats(2 * Cout + (1 if sync else 0), x.device)
+        stats = ext[:2 * Cout] if sync else ext
         raw = _ConvFn.forward_impl(ctx, x, weight, bias, spec, Cout, stats)
         ctx.bias_feeds_bn = True
-        y, mean, rstd, scale, shift = K.bn_train_fwd(raw, stats, gamma, beta, eps, momentum, running_mean, running_var, residual, act)
-        ctx.act, ctx.has_res = act, residual is not None
+        if sync:
+            synced_stats(ext, Cout, raw.shape[0], group)
+        y, mean, rstd, scale, shift = K.bn_train_fwd(raw, ext, gamma, beta, eps, momentum, running_mean, running_var, residual, act, sync=sync)
+        ctx.act, ctx.has_res, ctx.group = act, residual is not None, group
+        ctx.count = ext[2 * Cout:] if sync else None
         ctx.save_for_backward(x, weight, raw, y, gamma, mean, rstd, scale, shift)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, weight, raw, y, gamma, mean, rstd, scale, shift = ctx.saved_tensors
-        graw, gres, gg, gb_bn = K.bn_bwd(raw, y, gy.contiguous(), gamma, mean, rstd, scale, shift, ctx.act, ctx.has_res)
+        sync = (_group_sum(ctx.group), ctx.count) if ctx.group is not None else None
+        graw, gres, gg, gb_bn = K.bn_bwd(raw, y, gy.contiguous(), gamma, mean, rstd, scale, shift, ctx.act, ctx.has_res, sync=sync)
         n = ctx.needs_input_grad
         gx, gw, gb = _ConvFn.backward_impl(ctx, x, weight, graw, n[0], n[1], n[2])
-        return gx, gw, gb, None, None, gg, gb_bn, gres, None, None, None, None, None
+        return gx, gw, gb, None, None, gg, gb_bn, gres, None, None, None, None, None, None
 
 
 def conv_bn_act_train(x, weight, bias, spec, Cout, bn, residual=None, act=1):
     """Training-mode conv -> BatchNorm module `bn` -> (+residual) -> act, one autograd node (see _ConvBNActFn)."""
-    if spec.out_rows <= 1:
+    group = sync_group(bn)
+    if spec.out_rows <= 1 and group is None:
         raise ValueError("Expected more than 1 value per channel when training")     # torch's own train-mode BN error
     _BN_TOUCHED.append(bn)
     return _ConvBNActFn.apply(x, weight, bias, spec, Cout, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, float(bn.eps),
-                              float(bn.momentum), act)
+                              float(bn.momentum), act, group)
 
 
 _BN_FOLD_CACHE = {}

@@ -105,10 +105,11 @@ extern "C" int rd_colsum(const float *x, int64_t rows, int C, float *out, void *
     return colreduce(rows, C, ColsumF{x, C}, out, nullptr, S(stream), "rd_colsum");
 }
 
-__global__ void k_bn_finalize(const float *stats, float n, int C, const float *gamma, const float *beta, float eps, float momentum,
+__global__ void k_bn_finalize(const float *stats, float n_arg, int C, const float *gamma, const float *beta, float eps, float momentum,
                               float *running_mean, float *running_var, float *mean_out, float *rstd_out, float *scale, float *shift) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    const float n = n_arg > 0.f ? n_arg : stats[2 * C];
     double mean = (double)stats[c] / n;
     double var = (double)stats[C + c] / n - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -162,14 +163,23 @@ extern "C" int rd_affine_act(const float *x, int64_t rows, int C, const float *s
     return check_launch("rd_affine_act");
 }
 
+// stats[2C + 1]: (sum, sum of squares, row count) summed over the process group (SyncBatchNorm)
+extern "C" int rd_bn_finalize_sync(const float *stats, int C, const float *gamma, const float *beta, float eps, float momentum, float *running_mean,
+                                   float *running_var, float *mean, float *rstd, float *scale, float *shift, void *stream) {
+    k_bn_finalize<<<cdiv(C, 256), 256, 0, S(stream)>>>(stats, 0.f, C, gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale,
+                                                       shift);
+    return check_launch("rd_bn_finalize_sync");
+}
+
 // Train-mode BatchNorm forward in ONE launch: every block derives scale/shift of all C channels from the batch sums into LDS
 // (C / 256 channels per thread, a few double operations each), then streams its share of the rows; block 0 also writes
 // mean / rstd / scale / shift for the backward pass and updates the running statistics.
-__global__ __launch_bounds__(256) void k_bn_train_fwd(const float *__restrict__ x, int64_t n4, int C, const float *__restrict__ stats, float n,
+__global__ __launch_bounds__(256) void k_bn_train_fwd(const float *__restrict__ x, int64_t n4, int C, const float *__restrict__ stats, float n_arg,
                                                       const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float momentum,
                                                       float *running_mean, float *running_var, const float *__restrict__ residual, int act,
                                                       float *__restrict__ y, float *mean_out, float *rstd_out, float *scale_out, float *shift_out) {
     extern __shared__ float sc_sh[];  // [C] scale, [C] shift
+    const float n = n_arg > 0.f ? n_arg : stats[2 * C];      // synchronised statistics: the global row count rides behind the sums
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const double mean = (double)stats[c] / n;
         double var = (double)stats[C + c] / n - mean * mean;
@@ -239,11 +249,11 @@ __global__ __launch_bounds__(256) void k_bn_train_fwd(const float *__restrict__ 
     }
 }
 
-extern "C" int rd_bn_train_fwd(const float *x, int64_t rows, int C, const float *stats, const float *gamma, const float *beta, float eps,
-                               float momentum, float *running_mean, float *running_var, const float *residual, int act, float *y,
-                               float *mean, float *rstd, float *scale, float *shift, void *stream) {
-    RD_REQUIRE(rows > 0, "rd_bn_train_fwd: BatchNorm over zero rows");
-    RD_REQUIRE(C % 4 == 0 && C <= 8192 && act >= 0 && act <= 2, "rd_bn_train_fwd: C=%d must be a multiple of 4 (<= 8192), act in 0..2", C);
+static int bn_train_fwd_impl(const float *x, int64_t rows, float count, int C, const float *stats, const float *gamma, const float *beta, float eps,
+                             float momentum, float *running_mean, float *running_var, const float *residual, int act, float *y, float *mean,
+                             float *rstd, float *scale, float *shift, void *stream, const char *who) {
+    RD_REQUIRE(rows > 0, "%s: BatchNorm over zero rows", who);
+    RD_REQUIRE(C % 4 == 0 && C <= 8192 && act >= 0 && act <= 2, "%s: C=%d must be a multiple of 4 (<= 8192), act in 0..2", who, C);
     const int64_t n4 = rows * C / 4;
     // >= 8 float4 per thread amortise the per-block scale/shift table (C/256 channels per thread).  RD_BN_GRID_DIV / RD_BN_GRID_MAX
     // are tuning knobs: 4..16 float4 per thread and 512..4096 workgroups all measure 3.5-3.65 TB/s on the 57 MB launches (isolated) --
@@ -251,9 +261,25 @@ extern "C" int rd_bn_train_fwd(const float *x, int64_t rows, int C, const float 
     static const int gdiv = getenv("RD_BN_GRID_DIV") ? atoi(getenv("RD_BN_GRID_DIV")) : 8;
     static const int gmax = getenv("RD_BN_GRID_MAX") ? atoi(getenv("RD_BN_GRID_MAX")) : 2048;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n4, 256 * (int64_t)gdiv), gmax));
-    k_bn_train_fwd<<<blocks, 256, (size_t)2 * C * 4, S(stream)>>>(x, n4, C, stats, (float)rows, gamma, beta, eps, momentum, running_mean,
+    k_bn_train_fwd<<<blocks, 256, (size_t)2 * C * 4, S(stream)>>>(x, n4, C, stats, count, gamma, beta, eps, momentum, running_mean,
                                                                    running_var, residual, act, y, mean, rstd, scale, shift);
-    return check_launch("rd_bn_train_fwd");
+    return check_launch(who);
+}
+
+extern "C" int rd_bn_train_fwd(const float *x, int64_t rows, int C, const float *stats, const float *gamma, const float *beta, float eps,
+                               float momentum, float *running_mean, float *running_var, const float *residual, int act, float *y,
+                               float *mean, float *rstd, float *scale, float *shift, void *stream) {
+    return bn_train_fwd_impl(x, rows, (float)rows, C, stats, gamma, beta, eps, momentum, running_mean, running_var, residual, act, y, mean, rstd,
+                             scale, shift, stream, "rd_bn_train_fwd");
+}
+
+// SyncBatchNorm (tools/train.py:144-145, torch.nn.SyncBatchNorm.convert_sync_batchnorm): stats[2C + 1] = (sum, sum of squares, row
+// count) already summed over the process group; `rows` is this rank's share, which is what gets normalised here.
+extern "C" int rd_bn_train_fwd_sync(const float *x, int64_t rows, int C, const float *stats, const float *gamma, const float *beta, float eps,
+                                    float momentum, float *running_mean, float *running_var, const float *residual, int act, float *y,
+                                    float *mean, float *rstd, float *scale, float *shift, void *stream) {
+    return bn_train_fwd_impl(x, rows, 0.f, C, stats, gamma, beta, eps, momentum, running_mean, running_var, residual, act, y, mean, rstd, scale,
+                             shift, stream, "rd_bn_train_fwd_sync");
 }
 
 // ---- backward of y = act(x*scale + shift [+ residual]) with train-mode batch statistics
@@ -298,9 +324,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
                                                       int64_t n4, int C, const float *__restrict__ gamma, const float *__restrict__ mean,
                                                       const float *__restrict__ rstd, const float *__restrict__ scale,
                                                       const float *__restrict__ shift, int act, const float *__restrict__ sum_g,
-                                                      const float *__restrict__ sum_gx, float inv_n, float *__restrict__ gx,
-                                                      float *__restrict__ gres) {
+                                                      const float *__restrict__ sum_gx, float inv_n_arg, const float *__restrict__ count_dev,
+                                                      float *__restrict__ gx, float *__restrict__ gres) {
     extern __shared__ float tab[];  // [5][C]: A, B, D, scale, shift
+    const float inv_n = count_dev ? 1.0f / count_dev[0] : inv_n_arg;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const float r = rstd[c], A = (gamma ? gamma[c] : 1.f) * r;
         const float Bc = -A * r * (sum_gx[c] * inv_n);
@@ -332,23 +359,58 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
     }
 }
 
+static int bn_bwd_check(int64_t rows, int C, int act, int has_residual, const float *y, const float *grad_gamma, const float *grad_beta,
+                        const char *who) {
+    RD_REQUIRE(rows > 0, "%s: zero rows", who);
+    RD_REQUIRE(act >= 0 && act <= 2, "%s: bad act", who);
+    RD_REQUIRE(C <= 8192, "%s: C=%d > 8192", who, C);
+    RD_REQUIRE(!(act == 2 && has_residual), "%s: gelu with residual is not supported", who);
+    RD_REQUIRE(!(act == 1 && has_residual && y == nullptr), "%s: y is required for ReLU with a residual (the mask depends on the residual)", who);
+    RD_REQUIRE(grad_gamma && grad_beta, "%s: grad_gamma / grad_beta are required (zero-filled by the caller; the apply kernel reads them)", who);
+    return RD_OK;
+}
+
+static int bn_bwd_apply_launch(const float *x, const float *y, const float *grad_y, int64_t rows, int C, const float *gamma, const float *mean,
+                               const float *rstd, const float *scale, const float *shift, int act, int has_residual, const float *sum_gamma,
+                               const float *sum_beta, const float *count_dev, float *grad_x, float *grad_res, hipStream_t st, const char *who) {
+    int64_t n4 = rows * C / 4;
+    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n4, 256 * 8), 2048));   // >= 8 float4 per thread: the LDS table is amortised
+    k_bn_bwd_apply<<<blocks, 256, (size_t)5 * C * 4, st>>>(x, y, grad_y, n4, C, gamma, mean, rstd, scale, shift, act, sum_beta, sum_gamma,
+                                                           1.0f / (float)rows, count_dev, grad_x, has_residual ? grad_res : nullptr);
+    return check_launch(who);
+}
+
 extern "C" int rd_bn_bwd(const float *x, const float *y, const float *grad_y, int64_t rows, int C, const float *gamma, const float *mean,
                          const float *rstd, const float *scale, const float *shift, int act, int has_residual, float *grad_x,
                          float *grad_res, float *grad_gamma, float *grad_beta, void *stream) {
-    RD_REQUIRE(rows > 0, "rd_bn_bwd: zero rows");
-    RD_REQUIRE(act >= 0 && act <= 2, "rd_bn_bwd: bad act");
-    RD_REQUIRE(!(act == 2 && has_residual), "rd_bn_bwd: gelu with residual is not supported");
-    RD_REQUIRE(!(act == 1 && has_residual && y == nullptr), "rd_bn_bwd: y is required for ReLU with a residual (the mask depends on the residual)");
-    RD_REQUIRE(grad_gamma && grad_beta, "rd_bn_bwd: grad_gamma / grad_beta are required (zero-filled by the caller; the apply kernel reads them)");
-    hipStream_t st = S(stream);
-    int rc = colreduce(rows, C, BnBwdF{x, y, grad_y, mean, rstd, scale, shift, C, act}, grad_beta, grad_gamma, st, "rd_bn_bwd");
+    int rc = bn_bwd_check(rows, C, act, has_residual, y, grad_gamma, grad_beta, "rd_bn_bwd");
     if (rc) return rc;
-    int64_t n4 = rows * C / 4;
-    RD_REQUIRE(C <= 8192, "rd_bn_bwd: C=%d > 8192", C);
-    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n4, 256 * 8), 2048));   // >= 8 float4 per thread: the LDS table is amortised
-    k_bn_bwd_apply<<<blocks, 256, (size_t)5 * C * 4, st>>>(x, y, grad_y, n4, C, gamma, mean, rstd, scale, shift, act, grad_beta, grad_gamma, 1.0f / (float)rows,
-                                           grad_x, has_residual ? grad_res : nullptr);
-    return check_launch("rd_bn_bwd");
+    hipStream_t st = S(stream);
+    rc = colreduce(rows, C, BnBwdF{x, y, grad_y, mean, rstd, scale, shift, C, act}, grad_beta, grad_gamma, st, "rd_bn_bwd");
+    if (rc) return rc;
+    return bn_bwd_apply_launch(x, y, grad_y, rows, C, gamma, mean, rstd, scale, shift, act, has_residual, grad_gamma, grad_beta, nullptr, grad_x,
+                               grad_res, st, "rd_bn_bwd");
+}
+
+// SyncBatchNorm backward in two halves with the process group's all-reduce of [grad_gamma | grad_beta] between them: _reduce
+// accumulates this rank's sums (= its parameter gradients, as torch's SyncBatchNorm returns them), _apply takes the group-wide
+// sums and the group-wide row count (device scalar) for the input gradient.
+extern "C" int rd_bn_bwd_reduce(const float *x, const float *y, const float *grad_y, int64_t rows, int C, const float *mean, const float *rstd,
+                                const float *scale, const float *shift, int act, int has_residual, float *grad_gamma, float *grad_beta,
+                                void *stream) {
+    int rc = bn_bwd_check(rows, C, act, has_residual, y, grad_gamma, grad_beta, "rd_bn_bwd_reduce");
+    if (rc) return rc;
+    return colreduce(rows, C, BnBwdF{x, y, grad_y, mean, rstd, scale, shift, C, act}, grad_beta, grad_gamma, S(stream), "rd_bn_bwd_reduce");
+}
+
+extern "C" int rd_bn_bwd_apply(const float *x, const float *y, const float *grad_y, int64_t rows, int C, const float *gamma, const float *mean,
+                               const float *rstd, const float *scale, const float *shift, int act, int has_residual, const float *sum_gamma,
+                               const float *sum_beta, const float *count_dev, float *grad_x, float *grad_res, void *stream) {
+    int rc = bn_bwd_check(rows, C, act, has_residual, y, sum_gamma, sum_beta, "rd_bn_bwd_apply");
+    if (rc) return rc;
+    RD_REQUIRE(count_dev, "rd_bn_bwd_apply: the group-wide row count (device scalar) is required");
+    return bn_bwd_apply_launch(x, y, grad_y, rows, C, gamma, mean, rstd, scale, shift, act, has_residual, sum_gamma, sum_beta, count_dev, grad_x,
+                               grad_res, S(stream), "rd_bn_bwd_apply");
 }
 
 // ---------------------------------------------------------------------------------------------- sparse <-> dense

@@ -253,8 +253,8 @@ __global__ __launch_bounds__(256) void k_vfe_bwd_weight(const float *__restrict_
                                                         const float *__restrict__ weight, const float *__restrict__ geom,
                                                         const float *__restrict__ mean, const float *__restrict__ rstd,
                                                         const float *__restrict__ gamma, const float *__restrict__ dz,
-                                                        const float *__restrict__ dgamma, const float *__restrict__ dbeta, float inv_n,
-                                                        float *dW) {
+                                                        const float *__restrict__ dgamma, const float *__restrict__ dbeta, float inv_n_arg,
+                                                        const float *__restrict__ count_dev, float *dW) {
     __shared__ float w_lds[VFE_OUT * VFE_MAX_IN];
     __shared__ float red[8][VFE_OUT][VFE_MAX_IN];
     load_w(weight, 9 + n_feat, w_lds);
@@ -263,6 +263,7 @@ __global__ __launch_bounds__(256) void k_vfe_bwd_weight(const float *__restrict_
     constexpr int cin = 9 + n_feat;
     const int c = threadIdx.x & 31, sub = threadIdx.x >> 5;
     const float mu = mean[c], rs = rstd[c], ga = gamma[c];
+    const float inv_n = count_dev ? 1.0f / count_dev[0] : inv_n_arg;
     const float m1 = dbeta[c] * inv_n, m2 = dgamma[c] * inv_n;
     float acc[VFE_MAX_IN];
 #pragma unroll
@@ -291,17 +292,15 @@ __global__ __launch_bounds__(256) void k_vfe_bwd_weight(const float *__restrict_
     }
 }
 
-extern "C" int rd_vfe_backward(const float *points, int n_points, int n_feat, const int32_t *point_row, const int32_t *coords,
-                               const float *pillar_acc, const float *weight, const float *geom, const float *mean, const float *rstd,
-                               const float *gamma, const float *beta, const float *grad_out, const int32_t *argmax, int n_pillars,
-                               int n_valid, float *grad_weight, float *grad_gamma, float *grad_beta, float *ws, void *stream) {
-    RD_REQUIRE(9 + n_feat <= VFE_MAX_IN, "rd_vfe_backward: too many point features");
-    hipStream_t st = S(stream);
-    const int cin = 9 + n_feat;
-    RD_HIP(hipMemsetAsync(grad_weight, 0, (size_t)VFE_OUT * cin * 4, st));
+// scatter grad_out to the arg-max points (dz, in ws) + this rank's (grad_gamma, grad_beta)
+static int vfe_bwd_reduce(const float *points, int n_points, int n_feat, const int32_t *point_row, const int32_t *coords, const float *pillar_acc,
+                          const float *weight, const float *geom, const float *mean, const float *rstd, const float *gamma, const float *beta,
+                          const float *grad_out, const int32_t *argmax, int n_pillars, float *grad_gamma, float *grad_beta, float *ws,
+                          hipStream_t st, const char *who) {
+    RD_REQUIRE(9 + n_feat <= VFE_MAX_IN, "%s: too many point features", who);
     RD_HIP(hipMemsetAsync(grad_gamma, 0, VFE_OUT * 4, st));
     RD_HIP(hipMemsetAsync(grad_beta, 0, VFE_OUT * 4, st));
-    if (n_points <= 0 || n_pillars <= 0 || n_valid <= 0) return RD_OK;
+    if (n_points <= 0 || n_pillars <= 0) return RD_OK;
     float *dz = ws;
     RD_HIP(hipMemsetAsync(dz, 0, (size_t)n_points * VFE_OUT * 4, st));
     int64_t n_pc = (int64_t)n_pillars * VFE_OUT;
@@ -309,8 +308,50 @@ extern "C" int rd_vfe_backward(const float *points, int n_points, int n_feat, co
     int blocks = g_deterministic ? 1 : (int)std::min<int64_t>(cdiv(n_points, 8), 1024);
     VFE_DISPATCH(n_feat, k_vfe_bwd_reduce<NFC><<<blocks, 256, 0, st>>>(points, n_points, point_row, coords, pillar_acc, weight, geom, mean, rstd,
                                                                        gamma, beta, dz, grad_gamma, grad_beta));
+    return check_launch(who);
+}
+
+static int vfe_bwd_weight(const float *points, int n_points, int n_feat, const int32_t *point_row, const int32_t *coords, const float *pillar_acc,
+                          const float *weight, const float *geom, const float *mean, const float *rstd, const float *gamma,
+                          const float *sum_gamma, const float *sum_beta, int n_pillars, float inv_n, const float *count_dev, float *grad_weight,
+                          const float *ws, hipStream_t st, const char *who) {
+    const int cin = 9 + n_feat;
+    RD_HIP(hipMemsetAsync(grad_weight, 0, (size_t)VFE_OUT * cin * 4, st));
+    if (n_points <= 0 || n_pillars <= 0) return RD_OK;
     int blocks2 = g_deterministic ? 1 : (int)std::min<int64_t>(cdiv(n_points, 8), 256);
     VFE_DISPATCH(n_feat, k_vfe_bwd_weight<NFC><<<blocks2, 256, 0, st>>>(points, n_points, point_row, coords, pillar_acc, weight, geom, mean, rstd,
-                                                                        gamma, dz, grad_gamma, grad_beta, 1.0f / (float)n_valid, grad_weight));
-    return check_launch("rd_vfe_backward");
+                                                                        gamma, ws, sum_gamma, sum_beta, inv_n, count_dev, grad_weight));
+    return check_launch(who);
+}
+
+extern "C" int rd_vfe_backward(const float *points, int n_points, int n_feat, const int32_t *point_row, const int32_t *coords,
+                               const float *pillar_acc, const float *weight, const float *geom, const float *mean, const float *rstd,
+                               const float *gamma, const float *beta, const float *grad_out, const int32_t *argmax, int n_pillars,
+                               int n_valid, float *grad_weight, float *grad_gamma, float *grad_beta, float *ws, void *stream) {
+    hipStream_t st = S(stream);
+    if (n_valid <= 0) n_pillars = 0;
+    int rc = vfe_bwd_reduce(points, n_points, n_feat, point_row, coords, pillar_acc, weight, geom, mean, rstd, gamma, beta, grad_out, argmax, n_pillars,
+                            grad_gamma, grad_beta, ws, st, "rd_vfe_backward");
+    if (rc) return rc;
+    return vfe_bwd_weight(points, n_points, n_feat, point_row, coords, pillar_acc, weight, geom, mean, rstd, gamma, grad_gamma, grad_beta, n_pillars,
+                          n_valid > 0 ? 1.0f / (float)n_valid : 0.f, nullptr, grad_weight, ws, st, "rd_vfe_backward");
+}
+
+// SyncBatchNorm form of rd_vfe_backward: the caller all-reduces [grad_gamma | grad_beta] over the process group between the two
+// calls and passes the group-wide sums and the group-wide valid-point count (device scalar) to the second; `ws` carries dz across.
+extern "C" int rd_vfe_backward_reduce(const float *points, int n_points, int n_feat, const int32_t *point_row, const int32_t *coords,
+                                      const float *pillar_acc, const float *weight, const float *geom, const float *mean, const float *rstd,
+                                      const float *gamma, const float *beta, const float *grad_out, const int32_t *argmax, int n_pillars,
+                                      float *grad_gamma, float *grad_beta, float *ws, void *stream) {
+    return vfe_bwd_reduce(points, n_points, n_feat, point_row, coords, pillar_acc, weight, geom, mean, rstd, gamma, beta, grad_out, argmax, n_pillars,
+                          grad_gamma, grad_beta, ws, S(stream), "rd_vfe_backward_reduce");
+}
+
+extern "C" int rd_vfe_backward_weight(const float *points, int n_points, int n_feat, const int32_t *point_row, const int32_t *coords,
+                                      const float *pillar_acc, const float *weight, const float *geom, const float *mean, const float *rstd,
+                                      const float *gamma, const float *sum_gamma, const float *sum_beta, const float *count_dev, int n_pillars,
+                                      float *grad_weight, const float *ws, void *stream) {
+    RD_REQUIRE(count_dev, "rd_vfe_backward_weight: the group-wide valid-point count (device scalar) is required");
+    return vfe_bwd_weight(points, n_points, n_feat, point_row, coords, pillar_acc, weight, geom, mean, rstd, gamma, sum_gamma, sum_beta, n_pillars, 0.f,
+                          count_dev, grad_weight, ws, S(stream), "rd_vfe_backward_weight");
 }

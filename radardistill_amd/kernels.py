@@ -184,13 +184,25 @@ def vfe_seg_max(points, order, offsets, coords, weight, geom, scale, shift, n_pi
     return out, argmax, acc
 
 
-def vfe_backward(points, point_row, coords, acc, weight, geom, mean, rstd, gamma, beta, grad_out, argmax, n_valid):
+def vfe_backward(points, point_row, coords, acc, weight, geom, mean, rstd, gamma, beta, grad_out, argmax, n_valid, sync=None):
+    """sync = (allreduce, count_dev) as in bn_bwd (SyncBatchNorm): two launches with the group's all-reduce between them."""
     n, nf = points.shape[0], points.shape[1] - 1
     P = grad_out.shape[0]
     gw = torch.empty_like(weight)
-    gg = torch.empty(32, dtype=f32, device=points.device)
-    gb = torch.empty(32, dtype=f32, device=points.device)
+    g2 = torch.empty(64, dtype=f32, device=points.device)
+    gg, gb = g2[:32], g2[32:]
     ws = torch.empty(max(n, 1) * 32 + 128, dtype=f32, device=points.device)
+    if sync is not None:
+        allreduce, count_dev = sync
+        check(native.lib().rd_vfe_backward_reduce(_p(points), n, nf, _p(point_row), _p(coords), _p(acc), _p(weight), _p(geom), _p(mean), _p(rstd),
+                                                  _p(gamma), _p(beta), _p(_chk(grad_out, f32, "grad_out", 2)), _p(argmax), P, _p(gg), _p(gb),
+                                                  _p(ws), _stream()), "rd_vfe_backward_reduce")
+        tot = g2.clone()
+        allreduce(tot)
+        check(native.lib().rd_vfe_backward_weight(_p(points), n, nf, _p(point_row), _p(coords), _p(acc), _p(weight), _p(geom), _p(mean), _p(rstd),
+                                                  _p(gamma), _p(tot[:32]), _p(tot[32:]), _p(count_dev), P, _p(gw), _p(ws), _stream()),
+              "rd_vfe_backward_weight")
+        return gw, gg, gb
     check(native.lib().rd_vfe_backward(_p(points), n, nf, _p(point_row), _p(coords), _p(acc), _p(weight), _p(geom), _p(mean), _p(rstd),
                                        _p(gamma), _p(beta), _p(_chk(grad_out, f32, "grad_out", 2)), _p(argmax), P, int(n_valid),
                                        _p(gw), _p(gg), _p(gb), _p(ws), _stream()), "rd_vfe_backward")
@@ -432,11 +444,12 @@ def colsum(x):
 
 
 # ------------------------------------------------------------------------------------------ batch norm
-def bn_stats(x):
+def bn_stats(x, extra=0):
+    """-> (2C + extra,) zero-filled, [0, 2C) = per-channel sum and sum of squares over the rows."""
     _chk(x, f32, "bn input", 2)
     rows, C = x.shape
     from . import autograd as _A
-    stats = _A.zeros_stats(2 * C, x.device)
+    stats = _A.zeros_stats(2 * C + extra, x.device)
     check(native.lib().rd_bn_stats(_p(x), rows, C, _p(stats), _stream()), "rd_bn_stats")
     return stats
 
@@ -446,12 +459,13 @@ def bn_stats(x):
 BN_PROFILE = None
 
 
-def bn_train_fwd(x, stats, gamma, beta, eps, momentum, running_mean, running_var, residual, act):
-    """finalize + affine + residual + activation in one launch -> y, (mean, rstd, scale, shift) for the backward pass."""
+def bn_train_fwd(x, stats, gamma, beta, eps, momentum, running_mean, running_var, residual, act, sync=False):
+    """finalize + affine + residual + activation in one launch -> y, (mean, rstd, scale, shift) for the backward pass.
+    sync: stats holds 2C + 1 values (sums and the row count) already summed over the process group (SyncBatchNorm)."""
     _chk(x, f32, "bn input", 2)
     rows, C = x.shape
-    if _chk(stats, f32, "bn stats").numel() != 2 * C:
-        raise RuntimeError("bn_train_fwd: stats must hold 2*C sums")
+    if _chk(stats, f32, "bn stats").numel() != 2 * C + (1 if sync else 0):
+        raise RuntimeError("bn_train_fwd: stats must hold 2*C sums (+ the row count when synchronised)")
     if residual is not None and _chk(residual, f32, "residual", 2).shape != x.shape:
         raise RuntimeError("bn_train_fwd: residual shape mismatch")
     for t, nm in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
@@ -463,20 +477,26 @@ def bn_train_fwd(x, stats, gamma, beta, eps, momentum, running_mean, running_var
     if prof:
         e0 = timing_event(); e1 = timing_event()
         e0.record()
-    check(native.lib().rd_bn_train_fwd(_p(x), rows, C, _p(stats), _p(gamma), _p(beta), eps, momentum, _p(running_mean), _p(running_var),
-                                       _p(residual), act, _p(y), _p(side[0]), _p(side[1]), _p(side[2]), _p(side[3]), _stream()), "rd_bn_train_fwd")
+    fn = native.lib().rd_bn_train_fwd_sync if sync else native.lib().rd_bn_train_fwd
+    check(fn(_p(x), rows, C, _p(stats), _p(gamma), _p(beta), eps, momentum, _p(running_mean), _p(running_var),
+             _p(residual), act, _p(y), _p(side[0]), _p(side[1]), _p(side[2]), _p(side[3]), _stream()), "rd_bn_train_fwd")
     if prof:
         e1.record()
         BN_PROFILE.append((e0, e1, float(rows) * C * 4 * (3 if residual is not None else 2), (rows, C)))   # read x (+ residual), write y
     return y, side[0], side[1], side[2], side[3]
 
 
-def bn_finalize(stats, rows, C, gamma, beta, eps, momentum, running_mean, running_var):
+def bn_finalize(stats, rows, C, gamma, beta, eps, momentum, running_mean, running_var, sync=False):
+    """sync: stats[2C] is the row count, the whole buffer already summed over the process group (`rows` is ignored)."""
     dev = stats.device
     mean = torch.empty(C, dtype=f32, device=dev)
     rstd = torch.empty(C, dtype=f32, device=dev)
     scale = torch.empty(C, dtype=f32, device=dev)
     shift = torch.empty(C, dtype=f32, device=dev)
+    if sync:
+        check(native.lib().rd_bn_finalize_sync(_p(stats), C, _p(gamma), _p(beta), eps, momentum, _p(running_mean), _p(running_var),
+                                               _p(mean), _p(rstd), _p(scale), _p(shift), _stream()), "rd_bn_finalize_sync")
+        return mean, rstd, scale, shift
     check(native.lib().rd_bn_finalize(_p(stats), rows, C, _p(gamma), _p(beta), eps, momentum, _p(running_mean), _p(running_var),
                                       _p(mean), _p(rstd), _p(scale), _p(shift), _stream()), "rd_bn_finalize")
     return mean, rstd, scale, shift
@@ -494,7 +514,9 @@ def affine_act(x, scale, shift, residual, act):
     return y
 
 
-def bn_bwd(x, y, grad_y, gamma, mean, rstd, scale, shift, act, has_residual):
+def bn_bwd(x, y, grad_y, gamma, mean, rstd, scale, shift, act, has_residual, sync=None):
+    """sync = (allreduce, count_dev): SyncBatchNorm -- `allreduce(t)` sums a device tensor over the process group in place,
+    count_dev is the group-wide row count; the returned parameter gradients are this rank's own sums (torch semantics)."""
     _chk(x, f32, "x", 2); _chk(grad_y, f32, "grad_y", 2)
     rows, C = x.shape
     if grad_y.shape != x.shape or (y is not None and y.shape != x.shape):
@@ -506,6 +528,16 @@ def bn_bwd(x, y, grad_y, gamma, mean, rstd, scale, shift, act, has_residual):
     gg, gb = g2[:C], g2[C:]
     if act == 1 and not has_residual:
         y = None                                     # ReLU mask re-derived from x*scale + shift: one tensor less to stream
+    if sync is not None:
+        allreduce, count_dev = sync
+        check(native.lib().rd_bn_bwd_reduce(_p(x), _p(y), _p(grad_y), rows, C, _p(mean), _p(rstd), _p(scale), _p(shift), act, int(has_residual),
+                                            _p(gg), _p(gb), _stream()), "rd_bn_bwd_reduce")
+        tot = g2.clone()
+        allreduce(tot)
+        check(native.lib().rd_bn_bwd_apply(_p(x), _p(y), _p(grad_y), rows, C, _p(gamma), _p(mean), _p(rstd), _p(scale), _p(shift), act,
+                                           int(has_residual), _p(tot[:C]), _p(tot[C:]), _p(count_dev), _p(gx), _p(gres), _stream()),
+              "rd_bn_bwd_apply")
+        return gx, gres, gg, gb
     check(native.lib().rd_bn_bwd(_p(x), _p(y), _p(grad_y), rows, C, _p(gamma), _p(mean), _p(rstd), _p(scale), _p(shift), act,
                                  int(has_residual), _p(gx), _p(gres), _p(gg), _p(gb), _stream()), "rd_bn_bwd")
     return gx, gres, gg, gb

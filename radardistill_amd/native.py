@@ -96,6 +96,12 @@ SIGNATURES = {
     "rd_bn_finalize": (c_int, [_P, c_i64, c_int, _P, _P, c_f32, c_f32, _P, _P, _P, _P, _P, _P, _P]),
     "rd_affine_act": (c_int, [_P, c_i64, c_int, _P, _P, _P, c_int, _P, _P]),
     "rd_bn_bwd": (c_int, [_P, _P, _P, c_i64, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
+    "rd_bn_train_fwd_sync": (c_int, [_P, c_i64, c_int, _P, _P, _P, c_f32, c_f32, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P]),
+    "rd_bn_finalize_sync": (c_int, [_P, c_int, _P, _P, c_f32, c_f32, _P, _P, _P, _P, _P, _P, _P]),
+    "rd_bn_bwd_reduce": (c_int, [_P, _P, _P, c_i64, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
+    "rd_bn_bwd_apply": (c_int, [_P, _P, _P, c_i64, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "rd_vfe_backward_reduce": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
+    "rd_vfe_backward_weight": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P]),
     "rd_rows_to_dense": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "rd_dense_to_rows": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "rd_dcn_prep": (c_int, [_P, c_int, _P, c_int, c_int] + [c_int] * 10 + [_P, _P, _P]),

@@ -24,7 +24,7 @@ def run_block(seq, x):
             pad_next = int(m.padding[0])
             i += 1
             continue
-        assert isinstance(m, nn.Conv2d) and isinstance(mods[i + 1], nn.BatchNorm2d) and isinstance(mods[i + 2], nn.ReLU)
+        assert isinstance(m, nn.Conv2d) and isinstance(mods[i + 1], (nn.BatchNorm2d, nn.SyncBatchNorm)) and isinstance(mods[i + 2], nn.ReLU)
         conv = m
         if pad_next:
             conv = _PaddedView(m, pad_next)

@@ -33,7 +33,7 @@ class PFNLayerV2(nn.Module):
 class _PillarVFEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weight, gamma, beta, points, point_row, coords, acc, geom, scale, shift, mean, rstd, n_pillars, n_valid, order=None,
-                offsets=None):
+                offsets=None, sync=None):
         need_grad = mean is not None
         if order is not None:          # segmented path: the per-pillar sums come out of the same pass
             out, argmax, acc = K.vfe_seg_max(points, order, offsets, coords, weight.detach().contiguous(), geom, scale, shift, n_pillars, need_grad)
@@ -42,14 +42,15 @@ class _PillarVFEFn(torch.autograd.Function):
         if need_grad:
             ctx.save_for_backward(weight, gamma, beta, points, point_row, coords, acc, geom, mean, rstd, argmax)
             ctx.n_valid = n_valid
+            ctx.sync = sync
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         weight, gamma, beta, points, point_row, coords, acc, geom, mean, rstd, argmax = ctx.saved_tensors
         gw, gg, gb = K.vfe_backward(points, point_row, coords, acc, weight.detach(), geom, mean, rstd, gamma.detach(), beta.detach(),
-                                    grad_out.contiguous(), argmax, ctx.n_valid)
-        return (gw, gg, gb) + (None,) * 13
+                                    grad_out.contiguous(), argmax, ctx.n_valid, sync=ctx.sync)
+        return (gw, gg, gb) + (None,) * 14
 
 
 class DynamicPillarVFESimple2D(VFETemplate):
@@ -128,6 +129,8 @@ class DynamicPillarVFESimple2D(VFETemplate):
         w, bn = pfn.linear.weight, pfn.norm
         # default: points grouped by pillar, one wavefront per pillar, shuffle reductions, no float atomics (vfe_seg.hip);
         # RD_VFE_SEG=0: the first version (per-point lanes + 64-bit atomicMax into a packed buffer)
+        if P == 0 and bn.training and A.sync_group(bn) is not None:
+            raise RuntimeError("SyncBatchNorm VFE: this rank's batch has no in-range point; every rank must contribute to the statistics")
         seg = P > 0 and os.environ.get("RD_VFE_SEG", "1") != "0"
         if seg:
             return self._forward_segmented(batch_dict, points, point_row, coords, P, n_valid, g, w, bn)
@@ -136,13 +139,15 @@ class DynamicPillarVFESimple2D(VFETemplate):
             feats = points.new_zeros((0, 32))
         elif bn.training:
             stats = K.vfe_linear_stats(points, point_row, coords, acc, w.detach().contiguous(), g)
-            if n_valid <= 1:
+            sync = _sync_stats(bn, stats)
+            if n_valid <= 1 and sync is None:
                 raise ValueError("Expected more than 1 value per channel when training")
             A._BN_TOUCHED.append(bn)
             mean, rstd, scale, shift = K.bn_finalize(stats, n_valid, 32, bn.weight.detach(), bn.bias.detach(), float(bn.eps),
-                                                     float(bn.momentum), bn.running_mean, bn.running_var)
+                                                     float(bn.momentum), bn.running_mean, bn.running_var, sync=sync is not None)
             if torch.is_grad_enabled() and w.requires_grad:
-                feats = _PillarVFEFn.apply(w, bn.weight, bn.bias, points, point_row, coords, acc, g, scale, shift, mean, rstd, P, n_valid)
+                feats = _PillarVFEFn.apply(w, bn.weight, bn.bias, points, point_row, coords, acc, g, scale, shift, mean, rstd, P, n_valid,
+                                           None, None, sync)
             else:
                 feats, _ = K.vfe_linear_bn_relu_max(points, point_row, coords, acc, w.detach().contiguous(), g, scale, shift, P, False)
         else:
@@ -155,18 +160,31 @@ class DynamicPillarVFESimple2D(VFETemplate):
         return batch_dict
 
 
+def _sync_stats(bn, stats):
+    """SyncBatchNorm (--sync_bn): the 65-value statistics buffer (sums, sums of squares, valid-point count) is summed over the
+    process group in place -> (all-reduce callable, device count) for the backward, or None when this BatchNorm is local."""
+    group = A.sync_group(bn)
+    if group is None:
+        return None
+    reduce = A._group_sum(group)
+    reduce(stats)
+    return reduce, stats[64:]
+
+
 def _segmented(self, batch_dict, points, point_row, coords, P, n_valid, g, w, bn):
     offsets, order = K.vfe_group(point_row, P)
     wd = w.detach().contiguous()
     if bn.training:
         stats = K.vfe_seg_stats(points, order, offsets, coords, wd, g, P)
-        if n_valid <= 1:
+        sync = _sync_stats(bn, stats)
+        if n_valid <= 1 and sync is None:
             raise ValueError("Expected more than 1 value per channel when training")
         A._BN_TOUCHED.append(bn)
         mean, rstd, scale, shift = K.bn_finalize(stats, n_valid, 32, bn.weight.detach(), bn.bias.detach(), float(bn.eps),
-                                                 float(bn.momentum), bn.running_mean, bn.running_var)
+                                                 float(bn.momentum), bn.running_mean, bn.running_var, sync=sync is not None)
         if torch.is_grad_enabled() and w.requires_grad:
-            feats = _PillarVFEFn.apply(w, bn.weight, bn.bias, points, point_row, coords, None, g, scale, shift, mean, rstd, P, n_valid, order, offsets)
+            feats = _PillarVFEFn.apply(w, bn.weight, bn.bias, points, point_row, coords, None, g, scale, shift, mean, rstd, P, n_valid, order, offsets,
+                                       sync)
         else:
             feats, _, _ = K.vfe_seg_max(points, order, offsets, coords, wd, g, scale, shift, P, False)
     else:

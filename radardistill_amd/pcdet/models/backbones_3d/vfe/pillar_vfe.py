@@ -123,7 +123,8 @@ class PillarVFE(VFETemplate):
         coords = batch_dict['voxel_coords'].int().contiguous()
         geom = (self.voxel_x, self.voxel_y, self.voxel_z, self.x_offset, self.y_offset, self.z_offset)
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        if len(self.pfn_layers) == 1 and self.use_norm and not needs_grad and self.num_filters[0] <= 64:
+        synced = self.use_norm and self.training and A.sync_group(self.pfn_layers[0].norm) is not None
+        if len(self.pfn_layers) == 1 and self.use_norm and not needs_grad and not synced and self.num_filters[0] <= 64:
             batch_dict['pillar_features'] = self._forward_fused(voxels, num, coords, geom)
             return batch_dict
         M, P = voxels.shape[0], voxels.shape[1]

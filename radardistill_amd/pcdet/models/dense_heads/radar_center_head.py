@@ -84,7 +84,7 @@ class _BranchBatch:
                 if len(fc) != 2 or not isinstance(fc[0], nn.Sequential) or not isinstance(fc[1], nn.Conv2d):
                     return None
                 c1, bn, c2 = fc[0][0], fc[0][1], fc[1]
-                ok = (isinstance(c1, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d) and c1.in_channels == 64 and c1.out_channels == 64
+                ok = (isinstance(c1, nn.Conv2d) and isinstance(bn, (nn.BatchNorm2d, nn.SyncBatchNorm)) and c1.in_channels == 64 and c1.out_channels == 64
                       and c2.in_channels == 64 and 1 <= c2.out_channels <= 4 and c2.bias is not None
                       and all(c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1) and c.groups == 1
                               for c in (c1, c2)))

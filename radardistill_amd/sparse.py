@@ -256,7 +256,7 @@ class SparseSequential(SparseModule):
 
 def apply_rowwise(m, feats):
     """BatchNorm1d / ReLU on (rows, C) features through the HIP kernels."""
-    if isinstance(m, nn.BatchNorm1d):
+    if isinstance(m, (nn.BatchNorm1d, nn.SyncBatchNorm)):
         if m.training:
             return A.bn_act_train(feats, m, None, act=0)
         return A.bn_act_eval(feats, m, None, act=0)

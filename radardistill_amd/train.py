@@ -332,6 +332,19 @@ def reference_param_groups(model):
     return params, [groups[0], groups[1]]
 
 
+def convert_sync_batchnorm(model, process_group=None):
+    """--sync_bn of the reference (tools/train.py:34,144-145): torch.nn.SyncBatchNorm.convert_sync_batchnorm(model) swaps every
+    BatchNorm container for a SyncBatchNorm one (same parameters, buffers and state_dict names).  The arithmetic stays in norm.hip /
+    vfe.hip: a train-mode layer all-reduces its (sum, sum of squares, count) in the forward and its (grad_gamma, grad_beta) in the
+    backward over the process group -- two small collectives per layer, values handed to the kernels in device memory -- and
+    normalises with the group-wide statistics (rd_bn_train_fwd_sync, rd_bn_bwd_reduce / rd_bn_bwd_apply, rd_vfe_backward_*).
+    Eval-mode layers (the frozen teacher) are untouched, as in torch."""
+    from . import autograd as A
+    model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model, process_group)
+    A.SYNC_BN[0] = True          # also covers layers whose containers are batched on the channel axis (CenterHead branches)
+    return model
+
+
 def build_optimizer(model, optim_cfg):
     if optim_cfg.OPTIMIZER != 'adam_onecycle':
         raise NotImplementedError("the distill config trains with adam_onecycle")

@@ -28,3 +28,15 @@ def test_flat_allreduce_matches_ddp_two_ranks(overlap, bucket_mb):
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_flat_check.py")]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DIST_FLAT_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_sync_batchnorm_two_ranks_equal_one_process_on_all_rows():
+    """--sync_bn (tools/train.py:144-145): tests/dist_syncbn_check.py -- two ranks holding different shares of the rows, BatchNorm
+    synchronised through rd_bn_train_fwd_sync / rd_bn_bwd_reduce / rd_bn_bwd_apply / rd_vfe_backward_{reduce,weight}, equal one process
+    on the concatenated rows (outputs, running statistics, input gradients, summed parameter gradients); then two optimizer steps of
+    the converted PillarNet keep the ranks' parameters bit-identical."""
+    env = dict(os.environ, RD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_syncbn_check.py")]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DIST_SYNCBN_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
