@@ -210,29 +210,47 @@ def main():
     main_prio = int(os.environ.get("RD_MAIN_PRIO", "0"))
     if main_prio:
         torch.cuda.set_stream(torch.cuda.Stream(device, priority=main_prio))
-    for it in range(args.warmup):
-        step(it)
-
     def barrier():
         D.barrier()
         torch.cuda.synchronize()
 
-    # Per-launch HIP events (the roofline's kernel durations) bracket ~300 launches of a step and cost ~1 ms of it, so only every
-    # `every`-th step of the timed region carries them (at least 3 steps); the averages are over those steps.
-    every = max(1, min(int(os.environ.get("RD_BENCH_PROFILE_EVERY", "4")), args.steps // 3 or 1))
+    # Roofline measurement.  Per-launch HIP events around ALL ~300 MFMA launches of a step cost ~1.3 ms of it (host time and lost
+    # overlap), so the work is split: the LAST warm-up step (untimed) carries events on every MFMA launch and ranks the
+    # instantiations by summed time; in the timed region only the launches of the dominant instantiation (and the >= 16 MB
+    # BatchNorm launches of the HBM figure) carry events, in every step.  With --warmup 0 there is no ranking step: every MFMA
+    # launch of every `every`-th timed step is instrumented instead (at least 3 steps).
+    K.prefill_event_pool(min(30000, 900 * 4 + 260 * (args.steps + 3)))      # timing events (and their HIP handles) created outside the timed region
+    rank_prof = None
+    for it in range(args.warmup):
+        if it == args.warmup - 1 and not os.environ.get("RD_BENCH_NO_HOOKS"):
+            K.CONV_PROFILE, K.WGRAD_PROFILE = [], []
+        step(it)
+    if K.CONV_PROFILE is not None:
+        torch.cuda.synchronize()
+        rank_prof, K.CONV_PROFILE, K.WGRAD_PROFILE = K.CONV_PROFILE + K.WGRAD_PROFILE, None, None
+        by = {}
+        for a_, b_, _, _, shp in rank_prof:
+            by[shp[5]] = by.get(shp[5], 0.0) + a_.elapsed_time(b_)
+        K.PROFILE_TAGS = {max(by, key=lambda k: by[k])} if by else None
+    every = 1 if rank_prof is not None else max(1, min(int(os.environ.get("RD_BENCH_PROFILE_EVERY", "4")), args.steps // 3 or 1))
     hooked = [it for it in range(args.warmup, args.warmup + args.steps) if (it - args.warmup) % every == 0]
     if os.environ.get("RD_BENCH_NO_HOOKS"):          # diagnostic: cost of the per-launch HIP events themselves
         hooked = []
-    K.prefill_event_pool(min(30000, 900 * (len(hooked) + 3)))      # timing events created (and their HIP handles) outside the timed region
     prof, bnprof, wprof = [], [], []
     barrier()
     t0 = time.perf_counter()
     for it in range(args.warmup, args.warmup + args.steps):
         on = it in hooked
         K.CONV_PROFILE, K.BN_PROFILE, K.WGRAD_PROFILE = (prof, bnprof, wprof) if on else (None, None, None)
+        if on and K.PROFILE_TAGS is not None:          # only the dominant kernel's family pays for its tag computation
+            if str(next(iter(K.PROFILE_TAGS))).startswith("wgrad"):
+                K.CONV_PROFILE = None
+            else:
+                K.WGRAD_PROFILE = None
         loss = step(it)
     barrier()
     dt = time.perf_counter() - t0
+    K.PROFILE_TAGS = None
     K.CONV_PROFILE = K.BN_PROFILE = K.WGRAD_PROFILE = None
     last_loss = float(loss.detach())
     # The timed steps overlap the teacher's kernels (side stream) with the student's, so a launch's event-to-event duration includes
@@ -270,21 +288,27 @@ def main():
         K.set_conv_math(args.math)
         other = {"conv_math": om, "value": round(args.batch * world * args.other_math_steps / odt, 3), "unit": "samples/sec",
                  "ms_per_step": round(odt / args.other_math_steps * 1e3, 3), "steps": args.other_math_steps}
-    roofline_note = (f"HIP events around every launch of the kernel in {len(hooked)} of the {args.steps} steps of the timed region "
-                     f"(every {every}th step: the events themselves cost ~1 ms per instrumented step)")
+    if rank_prof is not None:
+        roofline_note = (f"HIP events around every launch of this kernel in all {len(hooked)} steps of the timed region; it was chosen, and the "
+                         "per-kernel table below measured, with events on every MFMA launch of the last warm-up step")
+    else:
+        roofline_note = (f"HIP events around every MFMA launch in {len(hooked)} of the {args.steps} steps of the timed region "
+                         f"(every {every}th step: the events themselves cost ~1 ms per instrumented step)")
     prof_steps = max(len(hooked), 1)
     dt = D.max_over_ranks(dt, device)
 
     if rank == 0:
         print(f"[bench] {args.steps} steps in {dt:.3f} s on {world} GPU(s); peak HBM allocated {torch.cuda.max_memory_allocated(device) / 2**30:.1f} GiB, "
               f"reserved {torch.cuda.memory_reserved(device) / 2**30:.1f} GiB", file=sys.stderr, flush=True)
-        ht = np.array(host_t[-args.steps:]) * 1e3
+        ht = np.array(host_t[args.warmup:args.warmup + args.steps]) * 1e3
         print(f"[bench] host enqueue time per step (ms, no device sync): forward+loss {ht[:, 0].mean():.1f}  backward {ht[:, 1].mean():.1f}  "
               f"optimizer {ht[:, 2].mean():.1f}", file=sys.stderr, flush=True)
         samples = args.batch * world * args.steps
         # every MFMA convolution launch of the timed region: forward, data gradient (CONV_PROFILE) and weight gradient (WGRAD_PROFILE),
         # each tagged with the instantiation the C dispatch picks (kernels._kernel_tag / conv_wgrad)
-        prof = list(prof) + list(wprof or [])
+        timed = list(prof) + list(wprof or [])
+        prof = rank_prof if rank_prof is not None else timed          # the table over ALL instantiations: ranking step, or the timed region
+        rank_steps = 1 if rank_prof is not None else prof_steps
         all_ms = [a.elapsed_time(b) for a, b, _, _, _ in prof]
         all_flops = [(f if pairs is None else float(pairs.item()) * f) for _, _, pairs, f, _ in prof]
         if os.environ.get("RD_BENCH_SHAPES"):
@@ -292,10 +316,11 @@ def main():
             for ms, fl, (_, _, _, _, shape) in zip(all_ms, all_flops, prof):
                 a = agg.setdefault(shape, [0, 0.0, 0.0]); a[0] += 1; a[1] += ms; a[2] += fl
             for shape, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                print(f"[shape in_rows,Cin,Cout,taps,mode,kernel={shape}] launches/step {n / prof_steps:.1f} ms/step {ms / prof_steps:.3f} "
+                print(f"[shape in_rows,Cin,Cout,taps,mode,kernel={shape}] launches/step {n / rank_steps:.1f} ms/step {ms / rank_steps:.3f} "
                       f"TF/s {fl / (ms * 1e-3) / 1e12:.1f}", file=sys.stderr)
-        # roofline of the DOMINANT kernel = the MFMA instantiation with the largest summed time in the timed region, weight gradients
-        # included.  achieved = ALGORITHMIC flops (dense 2 k^2 Cin Cout rows, sparse 2 pairs Cin Cout) / launch duration.
+        # roofline of the DOMINANT kernel = the MFMA instantiation with the largest summed time, weight gradients included.
+        # achieved = ALGORITHMIC flops (dense 2 k^2 Cin Cout rows, sparse 2 pairs Cin Cout) / launch duration, over its
+        # launches inside the timed region.
         b3 = args.math == "bf16x3"
         by_kern, fl_kern, n_kern = {}, {}, {}
         for i, p in enumerate(prof):
@@ -304,9 +329,9 @@ def main():
             fl_kern[tag] = fl_kern.get(tag, 0.0) + all_flops[i]
             n_kern[tag] = n_kern.get(tag, 0) + 1
         dom = max(by_kern, key=lambda k: by_kern[k]) if by_kern else 128
-        sel = [i for i, p in enumerate(prof) if p[4][5] == dom]
-        kernel_ms = [all_ms[i] for i in sel]
-        flops = [all_flops[i] for i in sel]
+        sel = [p for p in timed if p[4][5] == dom]
+        kernel_ms = [a.elapsed_time(b) for a, b, _, _, _ in sel]
+        flops = [(f if pairs is None else float(pairs.item()) * f) for _, _, pairs, f, _ in sel]
         n_launch = len(sel)
         avg_ms = sum(kernel_ms) / max(n_launch, 1)
         achieved = (sum(flops) / max(n_launch, 1)) / (avg_ms * 1e-3) / 1e12 if n_launch else 0.0
@@ -368,10 +393,10 @@ def main():
                                      "launch shares the GPU with the other streams' kernels, which lengthens it while shortening the step",
                              "avg_launch_ms": round(iso[0], 4), "achieved": round(iso[1], 3), "frac": round(iso[1] / peak, 4)},
                          "launches_per_step": n_launch // max(prof_steps, 1), "measured": roofline_note, "avg_launch_ms": round(avg_ms, 4),
-                         "ms_per_step_by_kernel": {str(k): round(v / prof_steps, 3) for k, v in sorted(by_kern.items(), key=lambda kv: -kv[1])},
+                         "ms_per_step_by_kernel": {str(k): round(v / rank_steps, 3) for k, v in sorted(by_kern.items(), key=lambda kv: -kv[1])},
                          "algorithmic_tflops_by_kernel": {str(k): round(fl_kern[k] / (by_kern[k] * 1e-3) / 1e12, 1) for k in sorted(by_kern, key=lambda k: -by_kern[k])},
                          "time_share_of_step": round(sum(kernel_ms) / prof_steps / step_ms, 4),
-                         "all_mfma_conv_share_of_step": round(sum(all_ms) / prof_steps / step_ms, 4)},
+                         "all_mfma_conv_share_of_step": round(sum(all_ms) / rank_steps / step_ms, 4)},
         }
         # HBM side of the metric ("HBM GB/s vs peak"): the streaming train-mode BatchNorm forward (normalise + affine + residual + ReLU,
         # one launch per layer), algorithmic bytes = x (+ residual) read once, y written once; launches of >= 16 MB only (smaller maps

@@ -246,6 +246,7 @@ def timing_event():
 # Optional per-launch timing hook used by bench.py for the roofline of the dominant kernel (k_conv_igemm<128,2,2,false>):
 # a list to which (start_event, end_event, algorithmic_flops) of every such launch is appended.  None = off (no overhead).
 CONV_PROFILE = None
+PROFILE_TAGS = None          # None: every profiled launch gets its pair of events; a set: only launches of these instantiation tags
 
 
 def split_bf16(x):
@@ -317,6 +318,7 @@ def conv_fwd(x, weight_k, taps, bias, out_rows, Cout, ix, scale=None, shift=None
     tile = 128 if ((out_rows + 127) // 128) * ((Cout + 127) // 128) >= 384 else 64
     if prof:
         tile = _kernel_tag(ix, in_rows, out_rows, Cin, Cout, taps, in_split, tile)
+        prof = PROFILE_TAGS is None or tile in PROFILE_TAGS
     if prof:
         e0 = timing_event(); e1 = timing_event()
         e0.record()
@@ -353,8 +355,8 @@ def conv_dgrad(grad_out, weight_k, taps, in_rows, Cin, ix_bwd, nbr_keepalive=Non
         if nbr_keepalive.shape != (in_rows, taps) or nbr_keepalive.dtype != i32 or not nbr_keepalive.is_contiguous():
             raise RuntimeError(f"backward neighbour table shape {tuple(nbr_keepalive.shape)} != ({in_rows}, {taps})")
     gx = torch.empty((in_rows, Cin), dtype=f32, device=grad_out.device)
-    prof = CONV_PROFILE is not None and Cin > 64
     tile = 128 if ((in_rows + 127) // 128) * ((Cin + 127) // 128) >= 384 else 64
+    prof = CONV_PROFILE is not None and Cin > 64 and (PROFILE_TAGS is None or tile in PROFILE_TAGS)
     if prof:
         e0 = timing_event(); e1 = timing_event()
         e0.record()
@@ -387,6 +389,17 @@ def conv_wgrad(x, grad_out, taps, ix, nbr_keepalive=None, in_split=False, go_spl
     gw = _A.zeros_accum(Cout * taps * Cin, x.device).view(Cout, taps, Cin)          # zero-initialised accumulator (atomics)
     prof = WGRAD_PROFILE is not None
     if prof:
+        # which instantiation conv_wgrad_impl (conv.hip) launches: the Cin tile is 128 for Cin >= 128 in bf16x3 mode; in exact fp32
+        # only when that leaves >= 32 (tap, tile) pairs
+        b3 = get_conv_math() == "bf16x3" and Cout >= 64 and Cin >= 64
+        wide = Cin >= 128 if b3 else (Cin >= 128 and Cout >= 64 and taps * ((Cout + 127) // 128) * ((Cin + 127) // 128) >= 32)
+        tag = ("wgrad_b3_" if b3 else "wgrad_f32_") + ("deform_" if ix.mode == 3 else "") + ("128" if wide else "64")
+        if (get_conv_math() == "bf16x3" and ix.mode == 1 and taps == 9 and ix.KH == 3 and ix.KW == 3 and ix.stride == 1 and ix.pad == 1
+                and ix.Hin == ix.Hout and ix.Win == ix.Wout and not in_split and not go_split and Cin % 4 == 0 and Cout % 4 == 0 and Cin >= 32
+                and Cout >= 32 and in_rows == out_rows and os.environ.get("RD_WGRAD_D3", "1") != "0"):
+            tag = "wgrad_d3"
+        prof = PROFILE_TAGS is None or tag in PROFILE_TAGS
+    if prof:
         e0 = timing_event(); e1 = timing_event()
         e0.record()
     if in_split or go_split:
@@ -403,15 +416,6 @@ def conv_wgrad(x, grad_out, taps, ix, nbr_keepalive=None, in_split=False, go_spl
             if pairs is None:
                 pairs = (nbr_keepalive >= 0).sum()
                 nbr_keepalive._rd_pairs = pairs
-        # which instantiation conv_wgrad_impl (conv.hip) launches: the Cin tile is 128 for Cin >= 128 in bf16x3 mode; in exact fp32
-        # only when that leaves >= 32 (tap, tile) pairs
-        b3 = get_conv_math() == "bf16x3" and Cout >= 64 and Cin >= 64
-        wide = Cin >= 128 if b3 else (Cin >= 128 and Cout >= 64 and taps * ((Cout + 127) // 128) * ((Cin + 127) // 128) >= 32)
-        tag = ("wgrad_b3_" if b3 else "wgrad_f32_") + ("deform_" if ix.mode == 3 else "") + ("128" if wide else "64")
-        if (get_conv_math() == "bf16x3" and ix.mode == 1 and taps == 9 and ix.KH == 3 and ix.KW == 3 and ix.stride == 1 and ix.pad == 1
-                and ix.Hin == ix.Hout and ix.Win == ix.Wout and not in_split and not go_split and Cin % 4 == 0 and Cout % 4 == 0 and Cin >= 32
-                and Cout >= 32 and in_rows == out_rows and os.environ.get("RD_WGRAD_D3", "1") != "0"):
-            tag = "wgrad_d3"
         WGRAD_PROFILE.append((e0, e1, pairs, 2.0 * Cin * Cout if pairs is not None else 2.0 * out_rows * taps * Cin * Cout,
                               (in_rows, Cin, Cout, taps, ix.mode, tag)))
     return gw

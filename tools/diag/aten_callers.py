@@ -14,6 +14,7 @@ sys.path.insert(0, ROOT)
 import bench as B                                                              # noqa: E402
 
 COUNTS = collections.Counter()
+ELEMS = collections.Counter()          # elements of the largest tensor argument / result: which call sites move real data
 ON = [False]
 
 
@@ -28,9 +29,13 @@ def wrap(owner, name, label=None, pred=None):
     orig = getattr(owner, name)
 
     def f(*a, **k):
+        out = orig(*a, **k)
         if ON[0] and (pred is None or pred(*a, **k)):
-            COUNTS[(label or name, site())] += 1
-        return orig(*a, **k)
+            key = (label or name, site())
+            COUNTS[key] += 1
+            flat = [t for x in a for t in (x if isinstance(x, (list, tuple)) else [x])] + [out]
+            ELEMS[key] += max([t.numel() for t in flat if torch.is_tensor(t)] or [0])
+        return out
     setattr(owner, name, f)
 
 
@@ -72,8 +77,12 @@ def main():
     for (op, s), c in COUNTS.items():
         tot[op] += c
     print("totals:", dict(tot))
-    for (op, s), c in sorted(COUNTS.items(), key=lambda kv: -kv[1])[:90]:
+    for (op, s), c in sorted(COUNTS.items(), key=lambda kv: -kv[1])[:60]:
         print(f"{c:5d}  {op:18s} {s}")
+    print("---- by elements moved (ops that touch >= 1e5 elements per call)")
+    for key, e in sorted(ELEMS.items(), key=lambda kv: -kv[1])[:60]:
+        if e / COUNTS[key] >= 1e5 and key[0] not in ("reshape",):
+            print(f"{e / 1e6:9.2f} M elements  {COUNTS[key]:4d} x  {key[0]:18s} {key[1]}")
 
 
 if __name__ == "__main__":

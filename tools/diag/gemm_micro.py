@@ -39,6 +39,26 @@ def main():
     fl = 2.0 * rows * Cin * Cout
     by = 4.0 * (rows * Cin + Cin * Cout + rows * Cout)
     print(f"gemm {rows}x{Cin}->{Cout}: {ms * 1e3:.1f} us/launch  {fl / ms / 1e9:.1f} TF/s algorithmic  {by / ms / 1e6:.0f} GB/s algorithmic  math={K.get_conv_math()}")
+    if "--floors" in sys.argv:
+        # reference points for the same shape (diagnostic only): the BLAS library's plain GEMMs and a pure stream of the output size
+        def timed(fn, n=iters):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(n):
+                fn()
+            b.record(); torch.cuda.synchronize()
+            return a.elapsed_time(b) / n * 1e3
+        wt = torch.randn(Cin, Cout, device=dev)
+        out = torch.empty(rows, Cout, device=dev)
+        print(f"  torch.mm fp32            {timed(lambda: torch.mm(x, wt, out=out)):.1f} us")
+        xb, wb, ob = x.bfloat16(), wt.bfloat16(), out.bfloat16()
+        print(f"  torch.mm bf16 (bf16 out) {timed(lambda: torch.mm(xb, wb, out=ob)):.1f} us")
+        y = torch.empty(rows, Cout, device=dev)
+        print(f"  rd_affine_act on the output ({rows}x{Cout}: read + write) {timed(lambda: K.affine_act(y, None, None, None, 1)):.1f} us")
+        print(f"  out.zero_() ({rows * Cout * 4 / 1e6:.0f} MB write) {timed(lambda: out.zero_()):.1f} us")
 
 
 if __name__ == "__main__":
