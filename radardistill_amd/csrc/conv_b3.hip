@@ -89,17 +89,42 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
     const int m0 = row_tile * BM, n0 = col_tile * BN;
     const int ld_r = tid >> 3, ld_c = (tid & 7) * 4;
 
+    // ---- dense geometry (modes 1 / 2): (b, oy, ox) of every tile row is worked out ONCE (three integer divisions per row, by one
+    // thread per row) and kept in LDS; a tap's source row is then a handful of integer operations.  The first version evaluated
+    // src_row() -- divisions by the map size included -- for every (row, tap) in the pre-pass below and again per thread at every
+    // tap change: 80-105 VALU instructions each (ISA), a fixed cost that dominated short-K launches and was a quarter of the
+    // VALU stream of the 9-tap ones.
+    __shared__ int4 s_pix[BM];
+    const bool dense = !DEFORM && (a.ix.mode == 1 || a.ix.mode == 2);
+    if (dense && tid < BM) {
+        const int j = m0 + tid;
+        int4 q = make_int4(0, 0, 0, 0);
+        if (j < a.out_rows) {
+            const int t1 = j / a.ix.Wout;
+            q = make_int4(t1 / a.ix.Hout, t1 % a.ix.Hout, j - t1 * a.ix.Wout, 1);
+        }
+        s_pix[tid] = q;
+    }
     // ---- taps with a source row in this tile (the LDS array is free before the main loop: word 0 is the mask)
     int *s_mask = reinterpret_cast<int *>(lds);
     if (tid == 0) *s_mask = 0;
     __syncthreads();
     {
         int mask = 0;
-        for (int p = 0; p < AP; ++p) {
-            const int j = m0 + ld_r + 32 * p;
-            if ((tid & 7) == 0)
-                for (int t = 0; t < a.taps; ++t)
-                    if (src_row(a, j, t) >= 0) mask |= 1 << t;
+        if (dense) {
+            if (tid < BM) {
+                const int4 q = s_pix[tid];
+                if (q.w)
+                    for (int t = 0; t < a.taps; ++t)
+                        if (src_row_dense(a.ix, q.x, q.y, q.z, t) >= 0) mask |= 1 << t;
+            }
+        } else {
+            for (int p = 0; p < AP; ++p) {
+                const int j = m0 + ld_r + 32 * p;
+                if ((tid & 7) == 0)
+                    for (int t = 0; t < a.taps; ++t)
+                        if (src_row(a, j, t) >= 0) mask |= 1 << t;
+            }
         }
         if (mask) atomicOr(s_mask, mask);
     }
@@ -149,6 +174,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
                         sidx[p] = make_int4(-1, -1, -1, -1);
                     }
                 }
+            } else if (dense) {
+                const int ky = cur_tap / a.ix.KW, kx = cur_tap - ky * a.ix.KW;          // block-uniform
+#pragma unroll
+                for (int p = 0; p < AP; ++p) {
+                    const int4 q = s_pix[ld_r + 32 * p];
+                    rows[p] = q.w ? src_row_dense_k(a.ix, q.x, q.y, q.z, ky, kx) : -1;
+                }
             } else {
 #pragma unroll
                 for (int p = 0; p < AP; ++p) rows[p] = src_row(a, m0 + ld_r + 32 * p, cur_tap);
@@ -164,7 +196,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
                 if (sidx[p].z >= 0) v += sw[p][2] * *reinterpret_cast<const f32x4 *>(base + (int64_t)sidx[p].z * a.Cin);
                 if (sidx[p].w >= 0) v += sw[p][3] * *reinterpret_cast<const f32x4 *>(base + (int64_t)sidx[p].w * a.Cin);
             } else {
-                if (rows[p] >= 0) v = *reinterpret_cast<const f32x4 *>(a.in + (int64_t)rows[p] * a.Cin + kc + ld_c);
+                // unconditional load (row 0 stands in for "no source"; the host guarantees one readable row) + select: no exec-mask
+                // branch between the loads of a tile, so they issue back to back
+                const f32x4 g = *reinterpret_cast<const f32x4 *>(a.in + (int64_t)max(rows[p], 0) * a.Cin + kc + ld_c);
+                if (rows[p] >= 0) v = g;
             }
             R.ra[p] = v;
         }
@@ -179,11 +214,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
             }
         } else {
 #pragma unroll
-            for (int p = 0; p < BP; ++p) {
-                const int n = n0 + ld_r + 32 * p;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (n < a.Cout) v = *reinterpret_cast<const f32x4 *>(a.w + ((int64_t)n * a.taps + cur_tap) * a.Cin + kc + ld_c);
-                R.rb[p] = v;
+            for (int p = 0; p < BP; ++p) {          // weight rows past Cout read the last row: those columns are never stored
+                const int n = min(n0 + ld_r + 32 * p, a.Cout - 1);
+                R.rb[p] = *reinterpret_cast<const f32x4 *>(a.w + ((int64_t)n * a.taps + cur_tap) * a.Cin + kc + ld_c);
             }
         }
     };
@@ -333,8 +366,10 @@ int launch_dgrad_b3(const ConvArgs &a, hipStream_t st) {
 // Launch for Cout > 32 (narrower outputs stay on the exact-fp32 kernel: they are bandwidth-bound level-1 sparse convs).
 bool launch_conv_d3_b3(const ConvArgs &a, hipStream_t st);
 
-int launch_conv_b3(const ConvArgs &a, int mode, hipStream_t st) {
-    if (launch_conv_d3_b3(a, st)) return RD_OK;      // dense 3x3 stride 1: halo-staged kernel
+int launch_conv_b3(const ConvArgs &a_in, int mode, hipStream_t st) {
+    if (launch_conv_d3_b3(a_in, st)) return RD_OK;      // dense 3x3 stride 1: halo-staged kernel
+    ConvArgs a = a_in;
+    if (a.in_rows == 0) a.in = a.w;          // the gathered kernel loads row 0 for "no source" and discards it: keep that address readable
     const int64_t big_blocks = cdiv(a.out_rows, 128) * cdiv(a.Cout, 128);
     dim3 block(256);
     if (mode == 3) {
