@@ -324,10 +324,10 @@ def conv_fwd(x, weight_k, taps, bias, out_rows, Cout, ix, scale=None, shift=None
         e0.record()
     if in_split or w_split:
         check(native.lib().rd_conv_fwd_split(_p(x), int(in_split), in_rows, Cin, _p(weight_k), int(w_split), taps, _p(bias), _p(out), out_rows, Cout,
-                                             ctypes.byref(ix), _p(scale), _p(shift), _p(residual), int(relu), _p(stats), _stream()),
+                                             ix, _p(scale), _p(shift), _p(residual), int(relu), _p(stats), _stream()),
               "rd_conv_fwd_split")
     else:
-        check(native.lib().rd_conv_fwd(_p(x), in_rows, Cin, _p(weight_k), taps, _p(bias), _p(out), out_rows, Cout, ctypes.byref(ix),
+        check(native.lib().rd_conv_fwd(_p(x), in_rows, Cin, _p(weight_k), taps, _p(bias), _p(out), out_rows, Cout, ix,
                                        _p(scale), _p(shift), _p(residual), int(relu), _p(stats), _stream()), "rd_conv_fwd")
     if prof:
         e1.record()
@@ -360,7 +360,7 @@ def conv_dgrad(grad_out, weight_k, taps, in_rows, Cin, ix_bwd, nbr_keepalive=Non
     if prof:
         e0 = timing_event(); e1 = timing_event()
         e0.record()
-    check(native.lib().rd_conv_dgrad(_p(grad_out), out_rows, Cout, _p(weight_k), taps, _p(gx), in_rows, Cin, ctypes.byref(ix_bwd), _stream()),
+    check(native.lib().rd_conv_dgrad(_p(grad_out), out_rows, Cout, _p(weight_k), taps, _p(gx), in_rows, Cin, ix_bwd, _stream()),
           "rd_conv_dgrad")
     if prof:
         e1.record()
@@ -404,9 +404,9 @@ def conv_wgrad(x, grad_out, taps, ix, nbr_keepalive=None, in_split=False, go_spl
         e0.record()
     if in_split or go_split:
         check(native.lib().rd_conv_wgrad_split(_p(x), int(in_split), in_rows, Cin, _p(grad_out), int(go_split), out_rows, Cout, taps,
-                                               ctypes.byref(ix), _p(gw), _stream()), "rd_conv_wgrad_split")
+                                               ix, _p(gw), _stream()), "rd_conv_wgrad_split")
     else:
-        check(native.lib().rd_conv_wgrad(_p(x), in_rows, Cin, _p(grad_out), out_rows, Cout, taps, ctypes.byref(ix), _p(gw), _stream()),
+        check(native.lib().rd_conv_wgrad(_p(x), in_rows, Cin, _p(grad_out), out_rows, Cout, taps, ix, _p(gw), _stream()),
               "rd_conv_wgrad")
     if prof:
         e1.record()
@@ -432,7 +432,7 @@ def weight_layout(src, Cout, Cin, taps, kind, flip=False, out_shape=None):
 
 def weight_layout_multi(jobs, n):
     """jobs: ctypes array of native.LayoutJob (host); one launch for all of them."""
-    check(native.lib().rd_weight_layout_multi(ctypes.cast(jobs, ctypes.c_void_p), int(n), _stream()), "rd_weight_layout_multi")
+    check(native.lib().rd_weight_layout_multi(jobs, int(n), _stream()), "rd_weight_layout_multi")
 
 
 def colsum(x):
@@ -716,7 +716,7 @@ def center_targets(gt_boxes, cfg_struct):
     inds = torch.empty((c.n_heads, B, c.max_objs), dtype=torch.int64, device=dev)
     masks = torch.empty((c.n_heads, B, c.max_objs), dtype=torch.int64, device=dev)
     gb = torch.empty((c.n_heads, B, c.max_objs, 7), dtype=f32, device=dev)
-    check(native.lib().rd_center_targets(_p(gt_boxes), B, M, D, ctypes.byref(c), _p(hm), _p(tb), _p(inds), _p(masks), _p(gb), _stream()),
+    check(native.lib().rd_center_targets(_p(gt_boxes), B, M, D, c, _p(hm), _p(tb), _p(inds), _p(masks), _p(gb), _stream()),
           "rd_center_targets")
     return {"heatmaps": hm, "target_boxes": tb, "inds": inds, "masks": masks, "gt_box": gb}
 
@@ -978,8 +978,8 @@ def center_loss_fwd(cfg, maps, heatmaps, inds, masks, target_boxes, gt_box):
         raise RuntimeError("center_loss: target tensors must be (n_heads, B, K, ...)")
     out = torch.empty(4 * nh + 1, dtype=f32, device=maps.device)
     scale = torch.empty(4 * nh, dtype=f32, device=maps.device)
-    ws = torch.empty(int(native.lib().rd_center_loss_ws_floats(ctypes.byref(cfg))), dtype=f32, device=maps.device)
-    check(native.lib().rd_center_loss_fwd(ctypes.byref(cfg), _p(maps), _p(heatmaps), _p(inds), _p(masks), _p(target_boxes), target_boxes.shape[3],
+    ws = torch.empty(int(native.lib().rd_center_loss_ws_floats(cfg)), dtype=f32, device=maps.device)
+    check(native.lib().rd_center_loss_fwd(cfg, _p(maps), _p(heatmaps), _p(inds), _p(masks), _p(target_boxes), target_boxes.shape[3],
                                           _p(gt_box), gt_box.shape[3], _p(out), _p(scale), _p(ws), _stream()), "rd_center_loss_fwd")
     return out, scale, ws
 
@@ -989,6 +989,6 @@ def center_loss_bwd(cfg, maps, heatmaps, inds, masks, scale, ws, grad_loss):
     if grad_loss.numel() != 1:
         raise RuntimeError("center_loss_bwd: grad_loss must hold one value")
     grad = torch.empty_like(maps)
-    check(native.lib().rd_center_loss_bwd(ctypes.byref(cfg), _p(maps), _p(heatmaps), _p(inds), _p(masks), _p(scale), _p(ws), _p(grad_loss), _p(grad),
+    check(native.lib().rd_center_loss_bwd(cfg, _p(maps), _p(heatmaps), _p(inds), _p(masks), _p(scale), _p(ws), _p(grad_loss), _p(grad),
                                           _stream()), "rd_center_loss_bwd")
     return grad

@@ -159,7 +159,7 @@ class FusedAdamOneCycle:
                     arr[k].src = g.data_ptr() if g is not None else None
                     arr[k].dst = base + 4 * int(self.offsets[i])
                     arr[k].numel = self.params[i].numel()
-                check(native.lib().rd_pack_grads_list(ctypes.cast(arr, ctypes.c_void_p), len(part), _stream()), "rd_pack_grads_list")
+                check(native.lib().rd_pack_grads_list(arr, len(part), _stream()), "rd_pack_grads_list")
             self._works.append(dist.all_reduce(self.flat_grad[e0:e1], op=dist.ReduceOp.SUM, group=self.process_group, async_op=True))
 
     def zero_grad(self):
