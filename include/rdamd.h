@@ -176,8 +176,10 @@ int rd_get_conv_math(void);
 int rd_split_bf16(const float *x, int64_t n, void *out, void *stream);
 int rd_weight_layout_split(const float *src, void *dst, int Cout, int Cin, int taps, int kind, int flip, void *stream);
 /* The same conversion for MANY weights in one launch (all trainable conv weights once per optimizer step).  jobs_dev: device array of
- * jobs (kinds as rd_weight_layout_split, no tap flip); chunk c (one 256-thread workgroup) converts 256 groups of 4 destination
- * elements of job chunk_job[c] starting at group chunk_group[c]; the caller builds the chunk tables so that every job is covered. */
+ * jobs (kinds as rd_weight_layout_split, no tap flip); chunk c (one 256-thread workgroup) converts work item chunk_group[c] of job
+ * chunk_job[c] -- a 16 x 64 x <= 9 (slow axis x fast axis x taps) tile of the destination, staged through LDS so that both the
+ * source and the destination are touched in address order; a job has rd_weight_layout_split_items() work items, numbered from 0,
+ * and the caller builds the chunk tables so that every item of every job appears once. */
 typedef struct {
     const float *src;
     void *dst;
@@ -187,6 +189,7 @@ typedef struct {
  * kernel arguments).  Used for the weight gradients of a backward pass (kernel layout -> nn.Conv2d / nn.ConvTranspose2d layout). */
 #define RD_LAYOUT_MULTI_MAX 96
 int rd_weight_layout_multi(const rd_layout_job *jobs_host, int n_jobs, void *stream);
+int rd_weight_layout_split_items(int Cout, int Cin, int taps, int kind);
 int rd_weight_layout_split_multi(const rd_layout_job *jobs_dev, const int *chunk_job_dev, const int *chunk_group_dev, int n_chunks, void *stream);
 int rd_conv_fwd_split(const void *in, int in_is_split, int in_rows, int Cin, const void *weight_k, int w_is_split, int taps,
                       const float *bias, float *out, int out_rows, int Cout, const rd_conv_index *idx, const float *scale,

@@ -257,10 +257,9 @@ class _OperandCache:
             for i, (key, e, p) in enumerate(stale):
                 jobs[i].src, jobs[i].dst = p.data_ptr(), e[1].data_ptr()
                 jobs[i].Cout, jobs[i].Cin, jobs[i].taps, jobs[i].kind = e[3], e[4], e[5], e[6]
-                groups = (e[3] * e[4] * e[5]) // 4
-                starts = np.arange(0, groups, 256, dtype=np.int32)
-                cj.append(np.full(starts.shape, i, dtype=np.int32))
-                cg.append(starts)
+                items = np.arange(K.native.lib().rd_weight_layout_split_items(e[3], e[4], e[5], e[6]), dtype=np.int32)
+                cj.append(np.full(items.shape, i, dtype=np.int32))
+                cg.append(items)
             raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(device)
             cj_d = torch.from_numpy(np.concatenate(cj)).to(device)
             cg_d = torch.from_numpy(np.concatenate(cg)).to(device)

@@ -181,9 +181,13 @@ extern "C" int rd_gelu_grn_bwd(const float *grad_out, const float *a, const floa
     int rc = grn_check(B, hw, C, "rd_gelu_grn_bwd");
     if (rc) return rc;
     hipStream_t st = S(stream);
-    RD_HIP(hipMemsetAsync(S_ws, 0, (size_t)B * C * 4, st));
-    RD_HIP(hipMemsetAsync(grad_gamma, 0, (size_t)C * 4, st));
-    RD_HIP(hipMemsetAsync(grad_beta, 0, (size_t)C * 4, st));
+    if (grad_gamma == S_ws + (size_t)B * C && grad_beta == grad_gamma + C) {          // one [S | grad_gamma | grad_beta] buffer: one fill
+        RD_HIP(hipMemsetAsync(S_ws, 0, (size_t)(B + 2) * C * 4, st));
+    } else {
+        RD_HIP(hipMemsetAsync(S_ws, 0, (size_t)B * C * 4, st));
+        RD_HIP(hipMemsetAsync(grad_gamma, 0, (size_t)C * 4, st));
+        RD_HIP(hipMemsetAsync(grad_beta, 0, (size_t)C * 4, st));
+    }
     const bool det = g_deterministic != 0;
     const int rb = det ? 1 : (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(hw, 64), 64));
     k_grn_reduce<1><<<dim3(rb, (unsigned)cdiv(C, GRN_COLS), B), 256, 0, st>>>(grad_out, a, hw, C, nullptr, S_ws, det ? nullptr : grad_beta);

@@ -94,10 +94,19 @@ extern "C" int rd_center_targets(const float *gt_boxes, int B, int M, int box_di
     hipStream_t st = S(stream);
     const int64_t slots = (int64_t)cfg->n_heads * B * cfg->max_objs;
     RD_HIP(hipMemsetAsync(heatmaps, 0, (size_t)B * cfg->n_channels * cfg->fy * cfg->fx * 4, st));
-    RD_HIP(hipMemsetAsync(target_boxes, 0, (size_t)slots * box_dim * 4, st));
-    RD_HIP(hipMemsetAsync(inds, 0, (size_t)slots * 8, st));
-    RD_HIP(hipMemsetAsync(masks, 0, (size_t)slots * 8, st));
-    RD_HIP(hipMemsetAsync(gt_box, 0, (size_t)slots * 7 * 4, st));
+    {   // the four per-slot outputs: one fill when the caller carved them out of one allocation in this order (the Python host does)
+        char *tb = reinterpret_cast<char *>(target_boxes), *in = reinterpret_cast<char *>(inds), *mk = reinterpret_cast<char *>(masks),
+             *gb = reinterpret_cast<char *>(gt_box);
+        const size_t n_tb = (size_t)slots * box_dim * 4, n_in = (size_t)slots * 8, n_gb = (size_t)slots * 7 * 4;
+        if (in == tb + n_tb && mk == in + n_in && gb == mk + n_in) {
+            RD_HIP(hipMemsetAsync(tb, 0, n_tb + 2 * n_in + n_gb, st));
+        } else {
+            RD_HIP(hipMemsetAsync(tb, 0, n_tb, st));
+            RD_HIP(hipMemsetAsync(in, 0, n_in, st));
+            RD_HIP(hipMemsetAsync(mk, 0, n_in, st));
+            RD_HIP(hipMemsetAsync(gb, 0, n_gb, st));
+        }
+    }
     if (M == 0) return RD_OK;
     k_center_targets<<<B * M, 128, 0, st>>>(gt_boxes, B, M, box_dim, *cfg, heatmaps, target_boxes, inds, masks, gt_box);
     return check_launch("rd_center_targets");

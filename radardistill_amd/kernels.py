@@ -712,10 +712,21 @@ def center_targets(gt_boxes, cfg_struct):
     c = cfg_struct
     dev = gt_boxes.device
     hm = torch.empty((B, c.n_channels, c.fy, c.fx), dtype=f32, device=dev)
-    tb = torch.empty((c.n_heads, B, c.max_objs, D), dtype=f32, device=dev)
-    inds = torch.empty((c.n_heads, B, c.max_objs), dtype=torch.int64, device=dev)
-    masks = torch.empty((c.n_heads, B, c.max_objs), dtype=torch.int64, device=dev)
-    gb = torch.empty((c.n_heads, B, c.max_objs, 7), dtype=f32, device=dev)
+    # the four per-slot outputs share ONE allocation in the order the library fills them (one memset instead of four); slots * D * 4
+    # bytes is a multiple of 8 whenever slots is even -- otherwise pad so the int64 views stay aligned
+    slots = c.n_heads * B * c.max_objs
+    n_tb, n_i, n_gb = slots * D * 4, slots * 8, slots * 7 * 4
+    if n_tb % 8 == 0:
+        raw = torch.empty(n_tb + 2 * n_i + n_gb, dtype=torch.uint8, device=dev)
+        tb = raw[:n_tb].view(f32).view(c.n_heads, B, c.max_objs, D)
+        inds = raw[n_tb:n_tb + n_i].view(torch.int64).view(c.n_heads, B, c.max_objs)
+        masks = raw[n_tb + n_i:n_tb + 2 * n_i].view(torch.int64).view(c.n_heads, B, c.max_objs)
+        gb = raw[n_tb + 2 * n_i:].view(f32).view(c.n_heads, B, c.max_objs, 7)
+    else:
+        tb = torch.empty((c.n_heads, B, c.max_objs, D), dtype=f32, device=dev)
+        inds = torch.empty((c.n_heads, B, c.max_objs), dtype=torch.int64, device=dev)
+        masks = torch.empty((c.n_heads, B, c.max_objs), dtype=torch.int64, device=dev)
+        gb = torch.empty((c.n_heads, B, c.max_objs, 7), dtype=f32, device=dev)
     check(native.lib().rd_center_targets(_p(gt_boxes), B, M, D, c, _p(hm), _p(tb), _p(inds), _p(masks), _p(gb), _stream()),
           "rd_center_targets")
     return {"heatmaps": hm, "target_boxes": tb, "inds": inds, "masks": masks, "gt_box": gb}
@@ -797,8 +808,8 @@ def gelu_grn_bwd(grad_out, a, z, ssq, B, gamma):
     _chk(grad_out, f32, "gelu_grn grad_out", 2)
     rows, C = grad_out.shape
     gz = torch.empty_like(z)
-    gg = torch.empty(C, dtype=f32, device=z.device); gb = torch.empty(C, dtype=f32, device=z.device)
-    ws = torch.empty((B, C), dtype=f32, device=z.device)
+    buf = torch.empty((B + 2) * C, dtype=f32, device=z.device)          # [S scratch | grad_gamma | grad_beta]: zero-filled by ONE memset inside
+    ws, gg, gb = buf[:B * C], buf[B * C:(B + 1) * C], buf[(B + 1) * C:]
     check(native.lib().rd_gelu_grn_bwd(_p(grad_out), _p(a), _p(z), _p(ssq), B, rows // B, C, _p(gamma), _p(ws), _p(gz), _p(gg), _p(gb), _stream()),
           "rd_gelu_grn_bwd")
     return gz, gg, gb

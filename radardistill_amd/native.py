@@ -81,6 +81,7 @@ SIGNATURES = {
     "rd_split_bf16": (c_int, [_P, c_i64, _P, _P]),
     "rd_weight_layout_split": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "rd_weight_layout_multi": (c_int, [_P, c_int, _P]),
+    "rd_weight_layout_split_items": (c_int, [c_int, c_int, c_int, c_int]),
     "rd_weight_layout_split_multi": (c_int, [_P, _P, _P, c_int, _P]),
     "rd_center_loss_ws_floats": (c_i64, [_P]),
     "rd_center_loss_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, _P, _P, _P, _P]),

@@ -552,7 +552,8 @@ def test_operand_cache_multi_refresh_matches_single_conversions():
     what the per-weight conversion writes, for every operand kind, after torch-side updates and after the fused optimizer's epoch bump."""
     from radardistill_amd import autograd as A, kernels as K
     g = torch.Generator(device="cpu").manual_seed(4)
-    shapes = [((96, 3, 3, 64), 0, 96, 64, 9), ((128, 64, 3, 3), 1, 128, 64, 9), ((64, 128, 2, 2), 3, 128, 64, 4), ((256, 1024), 0, 256, 1024, 1)]
+    shapes = [((96, 3, 3, 64), 0, 96, 64, 9), ((128, 64, 3, 3), 1, 128, 64, 9), ((64, 128, 2, 2), 3, 128, 64, 4), ((256, 1024), 0, 256, 1024, 1),
+              ((64, 100, 4, 4), 3, 100, 64, 16), ((36, 72, 3, 3), 1, 36, 72, 9)]          # 16 taps (two tap chunks), ragged tile edges
     params = [torch.nn.Parameter(torch.randn(*sh, generator=g).to(DEV)) for sh, _, _, _, _ in shapes]
     cache = A._OperandCache()
 
