@@ -352,9 +352,9 @@ def main():
             64: ("k_conv_igemm%s<64,64> (gathered implicit-GEMM conv, 64x64 tiles)" % ("_b3" if b3 else ""), "k_conv_igemm_b3<64, 64" if b3 else "k_conv_igemm<64, 64"),
             "wgrad_d3": ("k_conv_wgrad_d3_b3 (weight gradient of dense stride-1 3x3 convs: 8x8-pixel grad_out tile + 10x10 input halo staged once, "
                          "all 9 taps per staged tile, ds_read_b64_tr_b16 fragments, 8 waves x (32 co x 32 ci x 9 taps))", "k_conv_wgrad_d3_b3"),
-            "wgrad_b3_128": ("k_conv_wgrad_b3<false,128> (weight gradient GEMM: M = Cout tile 128, N = Cin tile 128 of one tap, K = rows; row chunks "
-                             "combined with fp32 atomics)", "k_conv_wgrad_b3<false, 128"),
-            "wgrad_b3_64": ("k_conv_wgrad_b3<false,64> (weight gradient GEMM, Cin tile 64)", "k_conv_wgrad_b3<false, 64"),
+            "wgrad_b3_128": ("k_conv_wgrad_tr_b3<128> (gathered weight gradient GEMM: M = Cout tile 128, N = Cin tile 128 of one tap, K = rows; "
+                             "row-major LDS images read with ds_read_b64_tr_b16; row chunks combined with fp32 atomics)", "k_conv_wgrad_tr_b3<128"),
+            "wgrad_b3_64": ("k_conv_wgrad_tr_b3<64> (gathered weight gradient GEMM, Cin tile 64)", "k_conv_wgrad_tr_b3<64"),
             "wgrad_b3_deform_128": ("k_conv_wgrad_b3<true,128> (DCNv2 weight gradient: input rows blended from 4 bilinear corners while staged)", "k_conv_wgrad_b3<true, 128"),
             "wgrad_f32_128": ("k_conv_wgrad<false,128> (weight gradient GEMM, exact fp32 MFMA)", "k_conv_wgrad<false, 128"),
             "wgrad_f32_64": ("k_conv_wgrad<false,64> (weight gradient GEMM, exact fp32 MFMA, Cin tile 64)", "k_conv_wgrad<false, 64"),

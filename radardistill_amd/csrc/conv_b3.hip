@@ -601,10 +601,206 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_b3(const WgradArgsB3 a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- weight gradient, bf16x3, transposing reads
+// Second generation of k_conv_wgrad_b3 for the non-deformable cases (sparse, 1x1, strided and transposed layers; the dense
+// stride-1 3x3 ones have the halo kernel).  PMC on the first one: 18 VALU instructions per MFMA and 10 % MFMA busy -- every
+// element of both operands went through a 4x4 register transpose after its split, and every thread looked up FOUR source rows per
+// K step.  Here the LDS images stay row-major, [32-channel chunk][row of the K step][32 channels] in 64-byte rows, exactly as
+// the operands lie in memory: a thread owns ONE row of the step (one neighbour lookup) and four 16-byte pieces of it, splits each
+// and stores it with a plain 8-byte write (a wavefront covers 8 consecutive 64-byte rows: conflict-free); the k-major fragments
+// the 32x32x16 MFMA wants come out of ds_read_b64_tr_b16 (gfx950's transposing LDS read: 4 rows x 16 channels per 16-lane group),
+// as in conv_wgrad_d3.hip.  Same tiles, chunking, `any` skip and atomic epilogue as before.
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8 tr_frag32(const __bf16 *p) {
+    typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p));
+    const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p + 4 * 32));
+    const s16x8_t v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int TN>
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad_tr_b3(const WgradArgsB3 a) {
+    constexpr int T = 128;                       // Cout tile
+    constexpr int NJ = TN / 64;                  // 32-wide ci chunks per wave (wave tile 64 couts x TN/2 cins)
+    constexpr int GC = T / 32, XC = TN / 32;     // 32-channel chunks per operand
+    constexpr int PART_G = GC * KB3 * 32, PART_X = XC * KB3 * 32;          // bf16 elements per (hi or lo) image
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * (PART_G + PART_X)];
+    __shared__ int s_any;
+    __bf16 *Gh = lds, *Gl = Gh + PART_G, *Xh = Gl + PART_G, *Xl = Xh + PART_X;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int tile = blockIdx.y;
+    const int n_nt = (a.Cin + TN - 1) / TN, n_mt = (a.Cout + T - 1) / T;
+    const int t = tile / (n_mt * n_nt);
+    const int mt = (tile / n_nt) % n_mt, nt = tile % n_nt;
+    const int co0 = mt * T, ci0 = nt * TN;
+    const int r_begin = blockIdx.x * a.rows_per_block;
+    const int r_end = min(a.out_rows, r_begin + a.rows_per_block);
+    const int n_steps = (r_end - r_begin + KB3 - 1) / KB3;
+    const int lr = tid >> 3, lc = (tid & 7) * 4;     // this thread's row of the K step and its 4 channels inside every 32-channel chunk
+
+    f32x16 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // dense geometry: a (b, oy, ox) cursor at this thread's row, advanced by 32 rows per step without divisions
+    const bool dense = a.ix.mode == 1 || a.ix.mode == 2;
+    const int t_ky = dense ? t / max(a.ix.KW, 1) : 0, t_kx = dense ? t - t_ky * a.ix.KW : 0;
+    int cb = 0, cy = 0, cx = 0;
+    if (dense) {
+        const int j = r_begin + lr;
+        cx = j % a.ix.Wout;
+        cy = (j / a.ix.Wout) % a.ix.Hout;
+        cb = j / (a.ix.Wout * a.ix.Hout);
+    }
+    const bool co_vec = (a.Cout & 3) == 0;
+
+    f32x4 rg[GC], rx[XC];
+    int any_next = 0;
+    auto load_tile = [&](int s) {
+        const int j = r_begin + s * KB3 + lr;
+        int src = -1;
+        if (j < r_end) {
+            if (dense) {
+                src = src_row_dense_k(a.ix, cb, cy, cx, t_ky, t_kx);
+            } else {
+                const int tt = a.ix.flip ? (a.taps - 1 - t) : t;
+                src = a.ix.nbr[(int64_t)j * a.taps + tt];
+            }
+        }
+        if (dense) {
+            cx += KB3;
+            while (cx >= a.ix.Wout) {
+                cx -= a.ix.Wout;
+                if (++cy == a.ix.Hout) {
+                    cy = 0;
+                    ++cb;
+                }
+            }
+        }
+        any_next = src >= 0;
+        const float *xrow = a.in + (int64_t)max(src, 0) * a.Cin + ci0 + lc;
+#pragma unroll
+        for (int p = 0; p < XC; ++p) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (src >= 0 && ci0 + 32 * p + lc < a.Cin) v = *reinterpret_cast<const f32x4 *>(xrow + 32 * p);
+            rx[p] = v;
+        }
+        const float *grow = a.go + (int64_t)min(j, a.out_rows - 1) * a.Cout + co0 + lc;
+#pragma unroll
+        for (int p = 0; p < GC; ++p) {
+            f32x4 u = {0.f, 0.f, 0.f, 0.f};
+            const int co = co0 + 32 * p + lc;
+            if (j < r_end) {
+                if (co_vec) {
+                    if (co < a.Cout) u = *reinterpret_cast<const f32x4 *>(grow + 32 * p);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < a.Cout) u[e] = grow[32 * p + e];
+                }
+            }
+            rg[p] = u;
+        }
+    };
+    const int st_off = lr * 32 + lc;             // element offset of this thread's piece inside a chunk image
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int p = 0; p < GC; ++p) {
+            bf16x4 hi, lo;
+            if (a.go_split) unpack4(rg[p], hi, lo);
+            else split4(rg[p], hi, lo);
+            *reinterpret_cast<bf16x4 *>(Gh + p * KB3 * 32 + st_off) = hi;
+            *reinterpret_cast<bf16x4 *>(Gl + p * KB3 * 32 + st_off) = lo;
+        }
+#pragma unroll
+        for (int p = 0; p < XC; ++p) {
+            bf16x4 hi, lo;
+            if (a.in_split) unpack4(rx[p], hi, lo);
+            else split4(rx[p], hi, lo);
+            *reinterpret_cast<bf16x4 *>(Xh + p * KB3 * 32 + st_off) = hi;
+            *reinterpret_cast<bf16x4 *>(Xl + p * KB3 * 32 + st_off) = lo;
+        }
+    };
+
+    // fragment addressing (ds_read_b64_tr_b16): 16-lane group grp reads 4 rows x 16 channels; lane 4q + p of the group supplies the
+    // address of row q, channels 4p..4p+3 and receives channel (lane & 15) of the 4 rows.  Groups 0 / 1: channels 0-15 / 16-31 at
+    // k = 0..7, groups 2 / 3: the same channels at k = 8..15.
+    const int grp = lane >> 4, li = lane & 15, fq = li >> 2, fp = li & 3, fhh = grp >> 1, cbb = (grp & 1) * 16;
+    const int f_base = (8 * fhh + fq) * 32 + cbb + 4 * fp;          // + chunk * KB3 * 32 + ks * 16 * 32
+
+    if (tid == 0) s_any = 0;
+    if (n_steps > 0) load_tile(0);
+    for (int s = 0; s < n_steps; ++s) {
+        __syncthreads();                          // previous step's fragment reads are done
+        store_tile();
+        if (any_next) s_any = s + 1;              // tag = step index + 1: no reset pass needed
+        __syncthreads();
+        const bool any = s_any == s + 1;
+        if (s + 1 < n_steps) load_tile(s + 1);    // global loads of the next step fly under this step's MFMAs
+        if (any) {
+#pragma unroll
+            for (int ks = 0; ks < KB3 / 16; ++ks) {
+                bf16x8 ah[2], al[2], bh[NJ], bl[NJ];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int o = (wm * 2 + i) * KB3 * 32 + ks * 16 * 32 + f_base;
+                    ah[i] = tr_frag32(Gh + o);
+                    al[i] = tr_frag32(Gl + o);
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int o = (wn * NJ + j) * KB3 * 32 + ks * 16 * 32 + f_base;
+                    bh[j] = tr_frag32(Xh + o);
+                    bl[j] = tr_frag32(Xl + o);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    // ---- combine: acc[i][j][r] is (co = 8 (r >> 2) + (r & 3) + 4 (lane >> 5), ci = lane & 31) of the (i, j) 32 x 32 block
+    const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int ci = ci0 + (wn * NJ + j) * 32 + fr;
+        if (ci < a.Cin) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    const float v = acc[i][j][r];
+                    if (co < a.Cout && v != 0.f) atomicAdd(&a.gw[((int64_t)co * a.taps + t) * a.Cin + ci], v);
+                }
+        }
+    }
+}
+
 int launch_wgrad_b3(const float *in, int in_rows, int Cin, const float *go, int out_rows, int Cout, int taps, const rd_conv_index *idx, float *gw,
                     int rows_per_block, int64_t chunks, int tiles, int cin_tile, int in_split, int go_split, hipStream_t st) {
     WgradArgsB3 a{in, in_rows, Cin, go, out_rows, Cout, taps, *idx, gw, rows_per_block, in_split, go_split};
     dim3 grid((unsigned)chunks, (unsigned)tiles);
+    static const bool tr_off = getenv("RD_WGRAD_TR") && getenv("RD_WGRAD_TR")[0] == '0';          // A/B switch: the first-generation kernel
+    if (idx->mode != 3 && !tr_off) {
+        if (a.in_rows == 0) a.in = go;          // "no source" rows read row 0 and discard it: keep that address readable
+        if (cin_tile == 128) k_conv_wgrad_tr_b3<128><<<grid, 256, 0, st>>>(a);
+        else k_conv_wgrad_tr_b3<64><<<grid, 256, 0, st>>>(a);
+        return RD_OK;
+    }
     if (cin_tile == 128) {
         if (idx->mode == 3) k_conv_wgrad_b3<true, 128><<<grid, 256, 0, st>>>(a);
         else k_conv_wgrad_b3<false, 128><<<grid, 256, 0, st>>>(a);
