@@ -69,7 +69,18 @@ extern "C" int rd_split_bf16(const float *x, int64_t n, void *out, void *stream)
 
 // BT = true: data gradient on the forward weights, B[k][n] = w[k][tap][n] (see k_conv_igemm in conv.hip).  The weight tile then
 // arrives n-contiguous; every thread takes a 4 (k) x 4 (n) block, transposes it in registers and writes k-contiguous pieces.
-template <int BM, int BN, bool DEFORM, bool BT = false>
+// neighbour-table geometry (index mode 0) without the other modes' code
+__device__ __forceinline__ int table_row(const ConvArgs &a, int j, int t) {
+    if (j >= a.out_rows) return -1;
+    const int tt = a.ix.flip ? (a.taps - 1 - t) : t;
+    return a.ix.nbr[(int64_t)j * a.taps + tt];
+}
+
+// SPEC >= 0 fixes three block-uniform run-time switches at compile time (bit 0: dense geometry = index modes 1 / 2 instead of the
+// neighbour table, bit 1: weights pre-split, bit 2: input pre-split): as run-time flags each of them put a branch around every
+// operand piece in the K loop (ISA: the loop body was ~60 basic blocks), which kept the compiler from scheduling the loads and the
+// splits of a step together.  SPEC = -1 keeps all three as run-time values (the rarely used entry points).
+template <int BM, int BN, bool DEFORM, bool BT = false, int SPEC = -1>
 __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int MI = WM / 32, NI = WN / 32;
@@ -95,7 +106,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
     // tap change: 80-105 VALU instructions each (ISA), a fixed cost that dominated short-K launches and was a quarter of the
     // VALU stream of the 9-tap ones.
     __shared__ int4 s_pix[BM];
-    const bool dense = !DEFORM && (a.ix.mode == 1 || a.ix.mode == 2);
+    const bool dense = SPEC >= 0 ? (!DEFORM && (SPEC & 1)) : (!DEFORM && (a.ix.mode == 1 || a.ix.mode == 2));
+    const bool w_presplit = SPEC >= 0 ? ((SPEC & 2) != 0) : (a.w_split != 0);
+    const bool in_presplit = SPEC >= 0 ? ((SPEC & 4) != 0) : (a.in_split != 0);
     if (dense && tid < BM) {
         const int j = m0 + tid;
         int4 q = make_int4(0, 0, 0, 0);
@@ -123,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
                 const int j = m0 + ld_r + 32 * p;
                 if ((tid & 7) == 0)
                     for (int t = 0; t < a.taps; ++t)
-                        if (src_row(a, j, t) >= 0) mask |= 1 << t;
+                        if ((SPEC >= 0 && !DEFORM ? table_row(a, j, t) : src_row(a, j, t)) >= 0) mask |= 1 << t;
             }
         }
         if (mask) atomicOr(s_mask, mask);
@@ -183,7 +196,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
                 }
             } else {
 #pragma unroll
-                for (int p = 0; p < AP; ++p) rows[p] = src_row(a, m0 + ld_r + 32 * p, cur_tap);
+                for (int p = 0; p < AP; ++p)
+                    rows[p] = SPEC >= 0 ? table_row(a, m0 + ld_r + 32 * p, cur_tap) : src_row(a, m0 + ld_r + 32 * p, cur_tap);
             }
         }
 #pragma unroll
@@ -227,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
             bf16x4 hi, lo;
-            if (!DEFORM && a.in_split) unpack4(R.ra[p], hi, lo);     // block-uniform
+            if (!DEFORM && in_presplit) unpack4(R.ra[p], hi, lo);     // block-uniform
             else split4(R.ra[p], hi, lo);
             *reinterpret_cast<bf16x4 *>(Ah + off(ld_r + 32 * p)) = hi;
             *reinterpret_cast<bf16x4 *>(Al + off(ld_r + 32 * p)) = lo;
@@ -249,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
 #pragma unroll
             for (int p = 0; p < BP; ++p) {
                 bf16x4 hi, lo;
-                if (a.w_split) unpack4(R.rb[p], hi, lo);
+                if (w_presplit) unpack4(R.rb[p], hi, lo);
                 else split4(R.rb[p], hi, lo);
                 *reinterpret_cast<bf16x4 *>(Bh + off(ld_r + 32 * p)) = hi;
                 *reinterpret_cast<bf16x4 *>(Bl + off(ld_r + 32 * p)) = lo;
@@ -372,14 +386,38 @@ int launch_conv_b3(const ConvArgs &a_in, int mode, hipStream_t st) {
     if (a.in_rows == 0) a.in = a.w;          // the gathered kernel loads row 0 for "no source" and discards it: keep that address readable
     const int64_t big_blocks = cdiv(a.out_rows, 128) * cdiv(a.Cout, 128);
     dim3 block(256);
+    const dim3 g128(xcd_grid(cdiv(a.out_rows, 128), cdiv(a.Cout, 128))), g64(xcd_grid(cdiv(a.out_rows, 64), cdiv(a.Cout, 64)));
+    const bool big = big_blocks >= 384;
     if (mode == 3) {
-        if (big_blocks >= 384) k_conv_igemm_b3<128, 128, true><<<dim3(xcd_grid(cdiv(a.out_rows, 128), cdiv(a.Cout, 128))), block, 0, st>>>(a);
-        else k_conv_igemm_b3<64, 64, true><<<dim3(xcd_grid(cdiv(a.out_rows, 64), cdiv(a.Cout, 64))), block, 0, st>>>(a);
-    } else {
-        // (a 128x64 tile for the 8192-row layers -- 256 workgroups, one per CU -- was measured at 86 vs 116 TF/s for 64x64)
-        if (big_blocks >= 384) k_conv_igemm_b3<128, 128, false><<<dim3(xcd_grid(cdiv(a.out_rows, 128), cdiv(a.Cout, 128))), block, 0, st>>>(a);
-        else k_conv_igemm_b3<64, 64, false><<<dim3(xcd_grid(cdiv(a.out_rows, 64), cdiv(a.Cout, 64))), block, 0, st>>>(a);
+        if (big) k_conv_igemm_b3<128, 128, true><<<g128, block, 0, st>>>(a);
+        else k_conv_igemm_b3<64, 64, true><<<g64, block, 0, st>>>(a);
+        return RD_OK;
     }
+    // (a 128x64 tile for the 8192-row layers -- 256 workgroups, one per CU -- was measured at 86 vs 116 TF/s for 64x64)
+    static const bool spec_off = getenv("RD_CONV_SPEC") && getenv("RD_CONV_SPEC")[0] == '0';
+    const int spec = spec_off ? -1 : ((mode == 1 || mode == 2) ? 1 : 0) | (a.w_split ? 2 : 0) | (a.in_split ? 4 : 0);
+    // mid-size layers (fewer than 384 128x128 tiles): 64x64 tiles, except the SPARSE ones with Cout >= 128, which take 64 (rows) x 128
+    // (channels) -- the neighbour gather of a row tile is then done once per 128 output channels (measured, 17 k rows 256->256:
+    // 123.5 -> 110.5 us; the dense 1x1 projections lose 15 % with the same tile and stay on 64x64)
+    static const bool wide_off = getenv("RD_TILE_MID") && getenv("RD_TILE_MID")[0] == '0';
+    const bool wide_mid = !big && mode == 0 && a.Cout >= 128 && !wide_off;
+    const dim3 g64128(xcd_grid(cdiv(a.out_rows, 64), cdiv(a.Cout, 128)));
+#define RD_LAUNCH_SPEC(S)                                                                      \
+    case S:                                                                                    \
+        if (big) k_conv_igemm_b3<128, 128, false, false, S><<<g128, block, 0, st>>>(a);        \
+        else if (wide_mid) k_conv_igemm_b3<64, 128, false, false, S><<<g64128, block, 0, st>>>(a); \
+        else k_conv_igemm_b3<64, 64, false, false, S><<<g64, block, 0, st>>>(a);               \
+        break;
+    switch (spec) {
+        RD_LAUNCH_SPEC(2)          // table geometry, weights pre-split (sparse layers: the default configuration)
+        RD_LAUNCH_SPEC(3)          // dense geometry, weights pre-split (1x1, strided, transposed layers)
+        RD_LAUNCH_SPEC(6)
+        RD_LAUNCH_SPEC(7)
+    default:
+        if (big) k_conv_igemm_b3<128, 128, false><<<g128, block, 0, st>>>(a);
+        else k_conv_igemm_b3<64, 64, false><<<g64, block, 0, st>>>(a);
+    }
+#undef RD_LAUNCH_SPEC
     return RD_OK;
 }
 
