@@ -659,7 +659,10 @@ __device__ __forceinline__ bf16x8 tr_frag32(const __bf16 *p) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int TN>
+// SPEC >= 0: bit 0 = dense geometry (index modes 1 / 2) else the neighbour table; both operands plain fp32 and Cout % 4 == 0 (the
+// training step's configuration) -- block-uniform run-time flags otherwise put a branch around every staged piece.  SPEC = -1: all
+// of them stay run-time values.
+template <int TN, int SPEC = -1>
 __global__ __launch_bounds__(256, 2) void k_conv_wgrad_tr_b3(const WgradArgsB3 a) {
     constexpr int T = 128;                       // Cout tile
     constexpr int NJ = TN / 64;                  // 32-wide ci chunks per wave (wave tile 64 couts x TN/2 cins)
@@ -689,7 +692,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_tr_b3(const WgradArgsB3 a
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // dense geometry: a (b, oy, ox) cursor at this thread's row, advanced by 32 rows per step without divisions
-    const bool dense = a.ix.mode == 1 || a.ix.mode == 2;
+    const bool dense = SPEC >= 0 ? ((SPEC & 1) != 0) : (a.ix.mode == 1 || a.ix.mode == 2);
+    const bool go_presplit = SPEC >= 0 ? false : (a.go_split != 0), in_presplit = SPEC >= 0 ? false : (a.in_split != 0);
     const int t_ky = dense ? t / max(a.ix.KW, 1) : 0, t_kx = dense ? t - t_ky * a.ix.KW : 0;
     int cb = 0, cy = 0, cx = 0;
     if (dense) {
@@ -698,7 +702,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_tr_b3(const WgradArgsB3 a
         cy = (j / a.ix.Wout) % a.ix.Hout;
         cb = j / (a.ix.Wout * a.ix.Hout);
     }
-    const bool co_vec = (a.Cout & 3) == 0;
+    const bool co_vec = SPEC >= 0 ? true : ((a.Cout & 3) == 0);
 
     f32x4 rg[GC], rx[XC];
     int any_next = 0;
@@ -753,7 +757,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_tr_b3(const WgradArgsB3 a
 #pragma unroll
         for (int p = 0; p < GC; ++p) {
             bf16x4 hi, lo;
-            if (a.go_split) unpack4(rg[p], hi, lo);
+            if (go_presplit) unpack4(rg[p], hi, lo);
             else split4(rg[p], hi, lo);
             *reinterpret_cast<bf16x4 *>(Gh + p * KB3 * 32 + st_off) = hi;
             *reinterpret_cast<bf16x4 *>(Gl + p * KB3 * 32 + st_off) = lo;
@@ -761,7 +765,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_tr_b3(const WgradArgsB3 a
 #pragma unroll
         for (int p = 0; p < XC; ++p) {
             bf16x4 hi, lo;
-            if (a.in_split) unpack4(rx[p], hi, lo);
+            if (in_presplit) unpack4(rx[p], hi, lo);
             else split4(rx[p], hi, lo);
             *reinterpret_cast<bf16x4 *>(Xh + p * KB3 * 32 + st_off) = hi;
             *reinterpret_cast<bf16x4 *>(Xl + p * KB3 * 32 + st_off) = lo;
@@ -835,8 +839,17 @@ int launch_wgrad_b3(const float *in, int in_rows, int Cin, const float *go, int 
     static const bool tr_off = getenv("RD_WGRAD_TR") && getenv("RD_WGRAD_TR")[0] == '0';          // A/B switch: the first-generation kernel
     if (idx->mode != 3 && !tr_off) {
         if (a.in_rows == 0) a.in = go;          // "no source" rows read row 0 and discard it: keep that address readable
-        if (cin_tile == 128) k_conv_wgrad_tr_b3<128><<<grid, 256, 0, st>>>(a);
-        else k_conv_wgrad_tr_b3<64><<<grid, 256, 0, st>>>(a);
+        const bool plain = !in_split && !go_split && (Cout & 3) == 0;
+        const bool dense = idx->mode == 1 || idx->mode == 2;
+        if (cin_tile == 128) {
+            if (plain && dense) k_conv_wgrad_tr_b3<128, 1><<<grid, 256, 0, st>>>(a);
+            else if (plain) k_conv_wgrad_tr_b3<128, 0><<<grid, 256, 0, st>>>(a);
+            else k_conv_wgrad_tr_b3<128><<<grid, 256, 0, st>>>(a);
+        } else {
+            if (plain && dense) k_conv_wgrad_tr_b3<64, 1><<<grid, 256, 0, st>>>(a);
+            else if (plain) k_conv_wgrad_tr_b3<64, 0><<<grid, 256, 0, st>>>(a);
+            else k_conv_wgrad_tr_b3<64><<<grid, 256, 0, st>>>(a);
+        }
         return RD_OK;
     }
     if (cin_tile == 128) {
