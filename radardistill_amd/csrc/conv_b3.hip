@@ -387,7 +387,11 @@ int launch_conv_b3(const ConvArgs &a_in, int mode, hipStream_t st) {
     const int64_t big_blocks = cdiv(a.out_rows, 128) * cdiv(a.Cout, 128);
     dim3 block(256);
     const dim3 g128(xcd_grid(cdiv(a.out_rows, 128), cdiv(a.Cout, 128))), g64(xcd_grid(cdiv(a.out_rows, 64), cdiv(a.Cout, 64)));
-    const bool big = big_blocks >= 384;
+    // 1-tap layers (the ConvNeXt projections, 1x1 aggregations: K = Cin only) take 64x64 tiles whatever their size: alone the two
+    // tiles time the same (35-38 us for 8192x256->1024), inside the step the 32 KB workgroups find room beside the other streams'
+    // 64 KB ones sooner (step -0.5 %).  RD_GEMM_TILE64=0 restores the size rule.
+    static const bool gemm64 = !(getenv("RD_GEMM_TILE64") && getenv("RD_GEMM_TILE64")[0] == '0');
+    const bool big = big_blocks >= 384 && !(gemm64 && a.taps == 1);
     if (mode == 3) {
         if (big) k_conv_igemm_b3<128, 128, true><<<g128, block, 0, st>>>(a);
         else k_conv_igemm_b3<64, 64, true><<<g64, block, 0, st>>>(a);

@@ -319,6 +319,8 @@ def conv_fwd(x, weight_k, taps, bias, out_rows, Cout, ix, scale=None, shift=None
     prof = CONV_PROFILE is not None and Cout > 64 and ix.mode != 3
     tile = 128 if ((out_rows + 127) // 128) * ((Cout + 127) // 128) >= 384 else 64
     if prof:
+        if taps == 1 and get_conv_math() == "bf16x3" and os.environ.get("RD_GEMM_TILE64", "1") != "0":
+            tile = 64          # 1-tap layers: 64x64 tiles whatever the size (launch_conv_b3)
         tile = _kernel_tag(ix, in_rows, out_rows, Cin, Cout, taps, in_split, tile)
         prof = PROFILE_TAGS is None or tile in PROFILE_TAGS
     if prof:
