@@ -26,6 +26,31 @@ def test_library_exports_every_header_symbol():
         L.rd_rankgrid_bytes()          # the generated callers check their argument count
 
 
+def test_generated_caller_marshals_like_ctypes():
+    """csrc/_rdcall.so (generated from native.SIGNATURES): a struct pointer may be a ctypes Structure instance (its own storage),
+    an address or None; integers and floats are parsed directly; a wrong argument count or type is a TypeError, not a crash.
+    Host-only entry points, no GPU."""
+    import ctypes
+    from radardistill_amd import native
+    native.build()
+    L, C = native.lib(), native.ctypes_lib()
+    cfg = native.CenterLossCfg()
+    cfg.n_heads, cfg.B, cfg.K = 6, 8, 500
+    want = C.rd_center_loss_ws_floats(ctypes.byref(cfg))
+    assert want == 32 + 8 * 13 + 6 * 8 * 500 * 30
+    assert L.rd_center_loss_ws_floats(cfg) == want                              # structure instance
+    assert L.rd_center_loss_ws_floats(ctypes.addressof(cfg)) == want            # plain address
+    assert L.rd_center_loss_ws_floats(None) == 0                                # NULL
+    assert L.rd_weight_layout_split_items(256, 256, 9, 1) == C.rd_weight_layout_split_items(256, 256, 9, 1) == 16 * 4
+    assert L.rd_weight_layout_split_items(100, 64, 16, 8) == 4 * 2 * 2          # A = Cin 64 -> 4 tiles, B = Cout 100 -> 2, taps 16 -> 2 chunks
+    with pytest.raises(TypeError):
+        L.rd_center_loss_ws_floats("not a pointer")
+    with pytest.raises(TypeError):
+        L.rd_weight_layout_split_items(1, 2, 3)
+    msg = L.rd_last_error()
+    assert msg is None or isinstance(msg, bytes)
+
+
 def test_missing_extension_fails_loudly(monkeypatch):
     from radardistill_amd import native
     monkeypatch.setattr(native, "SO_PATH", "/nonexistent/librdamd.so")
