@@ -388,6 +388,10 @@ def main():
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "flops": "algorithmic (SURVEY 8(d)): dense 2*k*k*Cin*Cout*rows, sparse 2*pairs*Cin*Cout",
                          "algorithmic_flops_per_launch": round(sum(flops) / max(n_launch, 1)),
+                         # what `traffic` (PMC, all launches of this kernel in the profiled command) compares with: input + output +
+                         # weights touched once, averaged over the same launches (shape tuple = rows_in, Cin, Cout, taps)
+                         "algorithmic_bytes_per_launch": round(sum(4.0 * (p[4][0] * p[4][1] + p[4][0] * p[4][2] + p[4][3] * p[4][1] * p[4][2])
+                                                                   for p in sel) / max(n_launch, 1)),
                          "mfma_issue_frac": round(issue * achieved / peak, 4),
                          "isolated": None if iso is None else {
                              "note": "same launches in 2 extra steps with the stream overlaps (teacher || student, wgrad || dgrad) off: in the timed region a "
