@@ -270,6 +270,12 @@ int rd_bn_bwd_apply(const float *x, const float *y, const float *grad_y, int64_t
                     const float *rstd, const float *scale, const float *shift, int act, int has_residual, const float *sum_gamma,
                     const float *sum_beta, const float *count_dev, float *grad_x, float *grad_res, void *stream);
 
+/* Channel concatenation of two channels-last row tensors, torch.cat((a, b), dim=1) of base_bev_backbone.py:296 and
+ * radar_distill_final.py:121-124: out (rows, Ca + Cb) = [a | b]; rd_split2_rows is its backward, grad (rows, Ca + Cb) -> two
+ * CONTIGUOUS gradients (ATen's cat backward returns strided slices that every consumer copies).  Ca, Cb multiples of 4. */
+int rd_cat2_rows(const float *a, int Ca, const float *b, int Cb, int64_t rows, float *out, void *stream);
+int rd_split2_rows(const float *grad, int64_t rows, int Ca, int Cb, float *grad_a, float *grad_b, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * E. Sparse -> dense BEV (SparseConvTensor.dense(), spconv_backbone_2d.py:299) in channels-last, and back.
  * ---------------------------------------------------------------------------------------------- */

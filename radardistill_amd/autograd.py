@@ -832,6 +832,29 @@ def rows_to_nchw(rows, B, H, W):
     return rows.view(B, H, W, rows.shape[1]).permute(0, 3, 1, 2)
 
 
+class _Cat2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a_rows, b_rows):
+        ctx.c = (a_rows.shape[1], b_rows.shape[1])
+        return K.cat2_rows(a_rows, b_rows)
+
+    @staticmethod
+    def backward(ctx, g):
+        ga, gb = K.split2_rows(g.contiguous(), *ctx.c)
+        return ga, gb
+
+
+def cat_channels(a, b):
+    """torch.cat((a, b), dim=1) for two (B, C, H, W) maps in channels-last memory (base_bev_backbone.py:296,
+    radar_distill_final.py:121-124): one streaming launch forward, one backward that returns CONTIGUOUS gradients."""
+    if not (a.is_cuda and a.dtype == torch.float32 and a.shape[1] % 4 == 0 and b.shape[1] % 4 == 0) or os.environ.get("RD_CAT", "1") == "0":
+        return torch.cat((a, b), dim=1)
+    ar, B, H, W = nchw_to_rows(a)
+    br, _, _, _ = nchw_to_rows(b)
+    out = _Cat2Fn.apply(ar, br) if torch.is_grad_enabled() and (a.requires_grad or b.requires_grad) else K.cat2_rows(ar, br)
+    return rows_to_nchw(out, B, H, W)
+
+
 class _DWConvFn(torch.autograd.Function):
     """Depthwise KxK conv (padding K//2) on channels-last rows; weight is the nn.Conv2d parameter [C, 1, K, K]."""
 

@@ -444,3 +444,40 @@ extern "C" int rd_dense_to_rows(const float *dense, const int32_t *coords, int n
     k_rows_to_dense<<<(int)std::min<int64_t>(cdiv(n4, 256), 4096), 256, 0, S(stream)>>>(feats, coords, n4, C, H, W, const_cast<float *>(dense), 0);
     return check_launch("rd_dense_to_rows");
 }
+
+
+// ---------------------------------------------------------------------------------------------- channel concatenation of two row tensors
+// torch.cat((a, b), dim=1) of two channels-last maps (base_bev_backbone.py:296, radar_distill_final.py:121-124) and its backward
+// as ONE streaming launch each: out[r] = [a[r] | b[r]]; backward g -> (ga, gb) CONTIGUOUS.  ATen's cat backward hands out strided
+// slices of g, which every consumer then copied (`contiguous`) and autograd's fan-out adds walked at 1.6 TB/s.
+__global__ __launch_bounds__(256) void k_cat2_rows(const f32x4 *__restrict__ a, const f32x4 *__restrict__ b, int64_t rows, int ca4, int cb4,
+                                                   f32x4 *__restrict__ out, int to_out) {
+    const int c4 = ca4 + cb4;
+    const int64_t n = rows * c4;
+    f32x4 *aw = const_cast<f32x4 *>(a), *bw = const_cast<f32x4 *>(b);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / c4;
+        const int c = (int)(i - r * c4);
+        if (to_out) out[i] = c < ca4 ? a[r * ca4 + c] : b[r * cb4 + (c - ca4)];
+        else if (c < ca4) aw[r * ca4 + c] = out[i];
+        else bw[r * cb4 + (c - ca4)] = out[i];
+    }
+}
+
+extern "C" int rd_cat2_rows(const float *a, int Ca, const float *b, int Cb, int64_t rows, float *out, void *stream) {
+    RD_REQUIRE(Ca > 0 && Cb > 0 && Ca % 4 == 0 && Cb % 4 == 0, "rd_cat2_rows: channel counts %d, %d must be positive multiples of 4", Ca, Cb);
+    if (rows <= 0) return RD_OK;
+    const int64_t n = rows * (Ca + Cb) / 4;
+    k_cat2_rows<<<(unsigned)std::min<int64_t>(cdiv(n, 256 * 4), 4096), 256, 0, S(stream)>>>(reinterpret_cast<const f32x4 *>(a), reinterpret_cast<const f32x4 *>(b),
+                                                                                           rows, Ca / 4, Cb / 4, reinterpret_cast<f32x4 *>(out), 1);
+    return check_launch("rd_cat2_rows");
+}
+
+extern "C" int rd_split2_rows(const float *g, int64_t rows, int Ca, int Cb, float *ga, float *gb, void *stream) {
+    RD_REQUIRE(Ca > 0 && Cb > 0 && Ca % 4 == 0 && Cb % 4 == 0, "rd_split2_rows: channel counts %d, %d must be positive multiples of 4", Ca, Cb);
+    if (rows <= 0) return RD_OK;
+    const int64_t n = rows * (Ca + Cb) / 4;
+    k_cat2_rows<<<(unsigned)std::min<int64_t>(cdiv(n, 256 * 4), 4096), 256, 0, S(stream)>>>(reinterpret_cast<const f32x4 *>(ga), reinterpret_cast<const f32x4 *>(gb),
+                                                                                           rows, Ca / 4, Cb / 4, reinterpret_cast<f32x4 *>(const_cast<float *>(g)), 0);
+    return check_launch("rd_split2_rows");
+}

@@ -551,6 +551,25 @@ def bn_bwd(x, y, grad_y, gamma, mean, rstd, scale, shift, act, has_residual, syn
     return gx, gres, gg, gb
 
 
+def cat2_rows(a, b):
+    _chk(a, f32, "cat a", 2); _chk(b, f32, "cat b", 2)
+    if a.shape[0] != b.shape[0]:
+        raise RuntimeError("cat2_rows: row counts differ")
+    out = torch.empty((a.shape[0], a.shape[1] + b.shape[1]), dtype=f32, device=a.device)
+    check(native.lib().rd_cat2_rows(_p(a), a.shape[1], _p(b), b.shape[1], a.shape[0], _p(out), _stream()), "rd_cat2_rows")
+    return out
+
+
+def split2_rows(g, Ca, Cb):
+    _chk(g, f32, "cat grad", 2)
+    if g.shape[1] != Ca + Cb:
+        raise RuntimeError("split2_rows: channel counts do not add up")
+    ga = torch.empty((g.shape[0], Ca), dtype=f32, device=g.device)
+    gb = torch.empty((g.shape[0], Cb), dtype=f32, device=g.device)
+    check(native.lib().rd_split2_rows(_p(g), g.shape[0], Ca, Cb, _p(ga), _p(gb), _stream()), "rd_split2_rows")
+    return ga, gb
+
+
 # ------------------------------------------------------------------------------------------ sparse <-> dense
 def rows_to_dense(feats, coords, batch, H, W):
     _chk(feats, f32, "feats", 2); _chk(coords, i32, "coords", 2)

@@ -97,6 +97,8 @@ SIGNATURES = {
     "rd_bn_finalize": (c_int, [_P, c_i64, c_int, _P, _P, c_f32, c_f32, _P, _P, _P, _P, _P, _P, _P]),
     "rd_affine_act": (c_int, [_P, c_i64, c_int, _P, _P, _P, c_int, _P, _P]),
     "rd_bn_bwd": (c_int, [_P, _P, _P, c_i64, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
+    "rd_cat2_rows": (c_int, [_P, c_int, _P, c_int, c_i64, _P, _P]),
+    "rd_split2_rows": (c_int, [_P, c_i64, c_int, c_int, _P, _P, _P]),
     "rd_bn_train_fwd_sync": (c_int, [_P, c_i64, c_int, _P, _P, _P, c_f32, c_f32, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P]),
     "rd_bn_finalize_sync": (c_int, [_P, c_int, _P, _P, c_f32, c_f32, _P, _P, _P, _P, _P, _P, _P]),
     "rd_bn_bwd_reduce": (c_int, [_P, _P, _P, c_i64, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P]),

@@ -94,7 +94,7 @@ class BaseBEVBackboneV2(nn.Module):
         x = run_block(self.blocks[1], x_conv5)
         de = self.deblocks[0]
         up = D.conv_bn_act(x, de[0], de[1], None, act=1)
-        feat = run_block(self.blocks[0], torch.cat((x_conv4, up), dim=1))
+        feat = run_block(self.blocks[0], A.cat_channels(x_conv4, up))
         return up, feat
 
     def _lowp_engine(self, x_conv4, x_conv5):

@@ -110,10 +110,10 @@ class Radar_Distill(BaseBEVBackboneV2):
         ms = data_dict['radar_multi_scale_2d_features']
         spatial_features = ms['x_conv4']
         en_16x = self.encoder_1(spatial_features)
-        de_8x = self._dec(self.agg_1, torch.cat((self._dec(self.decoder_1, en_16x), spatial_features), dim=1))
+        de_8x = self._dec(self.agg_1, A.cat_channels(self._dec(self.decoder_1, en_16x), spatial_features))
         en_32x = self.encoder_2(en_16x)
-        de_16x = self._dec(self.agg_2, torch.cat((self._dec(self.decoder_2, en_32x), self.encoder_3(de_8x)), dim=1))
-        x_conv4 = self._dec(self.agg_3, torch.cat((self._dec(self.decoder_3, de_16x), de_8x), dim=1))
+        de_16x = self._dec(self.agg_2, A.cat_channels(self._dec(self.decoder_2, en_32x), self.encoder_3(de_8x)))
+        x_conv4 = self._dec(self.agg_3, A.cat_channels(self._dec(self.decoder_3, de_16x), de_8x))
         ms['radar_spatial_features_8x_2'] = x_conv4
         ms['radar_spatial_features_8x_1'] = de_8x
         up, feat = self.dense_enc(x_conv4, ms['x_conv5'])

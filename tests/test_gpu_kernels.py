@@ -676,3 +676,22 @@ def test_layernorm_rows_vs_torch(rows, C):
     close(xd.grad, xr.grad, rtol=1e-4, atol=1e-5, what="layernorm grad x")
     close(wd.grad, wr.grad, rtol=1e-4, atol=1e-5, what="layernorm grad gamma")
     close(bd.grad, br.grad, rtol=1e-4, atol=1e-5, what="layernorm grad beta")
+
+
+def test_cat_channels_vs_torch_cat():
+    """rd_cat2_rows / rd_split2_rows (torch.cat((a, b), dim=1) of two channels-last maps and its backward): bit-equal values and
+    gradients, and the gradients come back contiguous."""
+    from radardistill_amd import autograd as A
+    g = torch.Generator(device="cpu").manual_seed(2)
+    a = torch.randn(2, 12, 9, 7, generator=g).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    b = torch.randn(2, 8, 9, 7, generator=g).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    a2, b2 = a.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    out = A.cat_channels(a, b)
+    ref = torch.cat((a2, b2), dim=1)
+    assert out.shape == ref.shape and torch.equal(out, ref)
+    go = torch.randn(ref.shape, generator=g).to(DEV)
+    (out * go).sum().backward()
+    (ref * go).sum().backward()
+    assert torch.equal(a.grad, a2.grad) and torch.equal(b.grad, b2.grad)
+    with torch.no_grad():
+        assert torch.equal(A.cat_channels(a.detach(), b.detach()), ref.detach())
