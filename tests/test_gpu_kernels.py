@@ -695,3 +695,39 @@ def test_cat_channels_vs_torch_cat():
     assert torch.equal(a.grad, a2.grad) and torch.equal(b.grad, b2.grad)
     with torch.no_grad():
         assert torch.equal(A.cat_channels(a.detach(), b.detach()), ref.detach())
+
+
+@pytest.mark.parametrize("rows", [1, 33, 700, 4099])
+def test_small_sparse_conv_32_channels_epilogue_and_stats(rows):
+    """conv_small.hip (one wavefront per 32 output rows, fragments straight from global memory; bf16x3 mode, 32 -> 32 channels,
+    neighbour-table geometry): the full epilogue contract (bias, folded BatchNorm scale / shift, residual, ReLU), the fused column
+    statistics, the mirrored table of the data gradient (flip) and ragged row counts, against a float64 gather-and-matmul."""
+    A, K, SP = _mods()
+    K.set_conv_math("bf16x3")
+    rng = np.random.default_rng(rows)
+    n_in = rows + 5
+    nbr = rng.integers(-1, n_in, size=(rows, 9)).astype(np.int32)
+    nbr[rng.random((rows, 9)) < 0.4] = -1
+    x = rng.normal(size=(n_in, 32)).astype(np.float32)
+    w = (rng.normal(size=(32, 9, 32)) / np.sqrt(288)).astype(np.float32)
+    b, sc, sh = [rng.normal(size=32).astype(np.float32) for _ in range(3)]
+    res = rng.normal(size=(rows, 32)).astype(np.float32)
+    nbr_d = torch.from_numpy(nbr).to(DEV)
+    for flip in (False, True):
+        ix = K.conv_index_table(nbr_d, flip=flip)
+        pre = np.zeros((rows, 32))
+        for t in range(9):
+            src = nbr[:, 8 - t] if flip else nbr[:, t]
+            ok = src >= 0
+            pre[ok] += x[src[ok]].astype(np.float64) @ w[:, t, :].astype(np.float64).T
+        pre += b
+        out = K.conv_fwd(torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV), 9, torch.from_numpy(b).to(DEV), rows, 32, ix,
+                         scale=torch.from_numpy(sc).to(DEV), shift=torch.from_numpy(sh).to(DEV), residual=torch.from_numpy(res).to(DEV),
+                         relu=True, nbr_keepalive=nbr_d)
+        close(out, np.maximum(pre * sc + sh + res, 0.0), rtol=1e-4, atol=1e-5, what=f"epilogue flip={flip}")
+        stats = torch.zeros(64, device=DEV)
+        raw = K.conv_fwd(torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV), 9, torch.from_numpy(b).to(DEV), rows, 32, ix, stats=stats,
+                         nbr_keepalive=nbr_d)
+        close(raw, pre, rtol=1e-4, atol=1e-5, what="raw")
+        close(stats[:32], pre.sum(0), rtol=1e-4, atol=2e-4, what="column sums")
+        close(stats[32:], (pre * pre).sum(0), rtol=1e-4, atol=2e-4, what="column sums of squares")
