@@ -391,7 +391,8 @@ int launch_conv_b3(const ConvArgs &a_in, int mode, hipStream_t st) {
     // tiles time the same (35-38 us for 8192x256->1024), inside the step the 32 KB workgroups find room beside the other streams'
     // 64 KB ones sooner (step -0.5 %).  RD_GEMM_TILE64=0 restores the size rule.
     static const bool gemm64 = !(getenv("RD_GEMM_TILE64") && getenv("RD_GEMM_TILE64")[0] == '0');
-    const bool big = big_blocks >= 384 && !(gemm64 && a.taps == 1);
+    static const int big_min = getenv("RD_BIG_TILES") ? atoi(getenv("RD_BIG_TILES")) : 384;
+    const bool big = big_blocks >= big_min && !(gemm64 && a.taps == 1);
     if (mode == 3) {
         if (big) k_conv_igemm_b3<128, 128, true><<<g128, block, 0, st>>>(a);
         else k_conv_igemm_b3<64, 64, true><<<g64, block, 0, st>>>(a);
@@ -404,12 +405,14 @@ int launch_conv_b3(const ConvArgs &a_in, int mode, hipStream_t st) {
     // (channels) -- the neighbour gather of a row tile is then done once per 128 output channels (measured, 17 k rows 256->256:
     // 123.5 -> 110.5 us; the dense 1x1 projections lose 15 % with the same tile and stay on 64x64)
     static const bool wide_off = getenv("RD_TILE_MID") && getenv("RD_TILE_MID")[0] == '0';
-    const bool wide_mid = !big && mode == 0 && a.Cout >= 128 && !wide_off;
+    // ... and every sparse layer with exactly 128 output channels, big or not (75 k rows 128->128: 134 -> 116 us; twice the
+    // workgroups of the 128x128 tile, the same single column tile)
+    const bool wide_mid = mode == 0 && a.Cout >= 128 && !wide_off && (!big || a.Cout == 128);
     const dim3 g64128(xcd_grid(cdiv(a.out_rows, 64), cdiv(a.Cout, 128)));
 #define RD_LAUNCH_SPEC(S)                                                                      \
     case S:                                                                                    \
-        if (big) k_conv_igemm_b3<128, 128, false, false, S><<<g128, block, 0, st>>>(a);        \
-        else if (wide_mid) k_conv_igemm_b3<64, 128, false, false, S><<<g64128, block, 0, st>>>(a); \
+        if (wide_mid) k_conv_igemm_b3<64, 128, false, false, S><<<g64128, block, 0, st>>>(a);  \
+        else if (big) k_conv_igemm_b3<128, 128, false, false, S><<<g128, block, 0, st>>>(a);   \
         else k_conv_igemm_b3<64, 64, false, false, S><<<g64, block, 0, st>>>(a);               \
         break;
     switch (spec) {
