@@ -232,7 +232,9 @@ def main():
         for a_, b_, _, _, shp in rank_prof:
             by[shp[5]] = by.get(shp[5], 0.0) + a_.elapsed_time(b_)
         K.PROFILE_TAGS = {max(by, key=lambda k: by[k])} if by else None
-    every = 1 if rank_prof is not None else max(1, min(int(os.environ.get("RD_BENCH_PROFILE_EVERY", "4")), args.steps // 3 or 1))
+    # an event pair costs the stream ~2 x 4 us of marker packets, so even the dominant kernel's ~25 launches are timed in every SECOND
+    # step only (>= 3 steps), and the BatchNorm launches of the HBM figure in the first two instrumented steps
+    every = (2 if args.steps >= 6 else 1) if rank_prof is not None else max(1, min(int(os.environ.get("RD_BENCH_PROFILE_EVERY", "4")), args.steps // 3 or 1))
     hooked = [it for it in range(args.warmup, args.warmup + args.steps) if (it - args.warmup) % every == 0]
     if os.environ.get("RD_BENCH_NO_HOOKS"):          # diagnostic: cost of the per-launch HIP events themselves
         hooked = []
@@ -242,6 +244,8 @@ def main():
     for it in range(args.warmup, args.warmup + args.steps):
         on = it in hooked
         K.CONV_PROFILE, K.BN_PROFILE, K.WGRAD_PROFILE = (prof, bnprof, wprof) if on else (None, None, None)
+        if on and rank_prof is not None and it not in hooked[:2]:
+            K.BN_PROFILE = None
         if on and K.PROFILE_TAGS is not None:          # only the dominant kernel's family pays for its tag computation
             if str(next(iter(K.PROFILE_TAGS))).startswith("wgrad"):
                 K.CONV_PROFILE = None
@@ -289,8 +293,9 @@ def main():
         other = {"conv_math": om, "value": round(args.batch * world * args.other_math_steps / odt, 3), "unit": "samples/sec",
                  "ms_per_step": round(odt / args.other_math_steps * 1e3, 3), "steps": args.other_math_steps}
     if rank_prof is not None:
-        roofline_note = (f"HIP events around every launch of this kernel in all {len(hooked)} steps of the timed region; it was chosen, and the "
-                         "per-kernel table below measured, with events on every MFMA launch of the last warm-up step")
+        roofline_note = (f"HIP events around every launch of this kernel in {len(hooked)} of the {args.steps} steps of the timed region (every "
+                         f"{every}th: an event pair costs the stream two marker packets); it was chosen, and the per-kernel table below measured, "
+                         "with events on every MFMA launch of the last warm-up step")
     else:
         roofline_note = (f"HIP events around every MFMA launch in {len(hooked)} of the {args.steps} steps of the timed region "
                          f"(every {every}th step: the events themselves cost ~1 ms per instrumented step)")
@@ -412,7 +417,7 @@ def main():
             gbs = by_tot / (ms_tot * 1e-3) / 1e9
             out["roofline_hbm"] = {"bound": "hbm", "kernel": "k_bn_train_fwd (train-mode BatchNorm + residual + ReLU over rows, launches moving >= 16 MB)",
                                    "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                                   "traffic": None, "launches_per_step": len(big) // max(prof_steps, 1),
+                                   "traffic": None, "launches_per_step": len(big) // max(min(prof_steps, 2) if rank_prof is not None else prof_steps, 1),
                                    "avg_launch_ms": round(ms_tot / len(big), 4), "algorithmic_bytes_per_launch": int(by_tot / len(big)),
                                    "measured": "HIP events around every such launch inside the timed region (other streams' kernels run concurrently)"}
             ibig = [(a.elapsed_time(b), by) for a, b, by, _ in (iso_bn or []) if by >= 16e6]
