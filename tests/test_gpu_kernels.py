@@ -577,7 +577,7 @@ def test_pillar_vfe_training_and_multi_layer_golden(golden_dir, math):
                 ev = m({"voxels": v, "voxel_num_points": n, "voxel_coords": c, "batch_size": 2})["pillar_features"]
             close(ev, g[f"{tag}_eval_features"], what=f"{tag} eval features")
     finally:
-        K.set_conv_math("bf16x3")
+        K.set_conv_math("f32")
 
 
 def test_full_size_voxelizer_and_rulebook_pyramid_bit_exact():
@@ -704,6 +704,13 @@ def test_small_sparse_conv_32_channels_epilogue_and_stats(rows):
     statistics, the mirrored table of the data gradient (flip) and ragged row counts, against a float64 gather-and-matmul."""
     A, K, SP = _mods()
     K.set_conv_math("bf16x3")
+    try:
+        _small_sparse_case(K, rows)
+    finally:
+        K.set_conv_math("f32")          # the library's arithmetic mode is process-global: leave it as the other tests expect it
+
+
+def _small_sparse_case(K, rows):
     rng = np.random.default_rng(rows)
     n_in = rows + 5
     nbr = rng.integers(-1, n_in, size=(rows, 9)).astype(np.int32)
