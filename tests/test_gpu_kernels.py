@@ -738,3 +738,47 @@ def _small_sparse_case(K, rows):
         close(raw, pre, rtol=1e-4, atol=1e-5, what="raw")
         close(stats[:32], pre.sum(0), rtol=1e-4, atol=2e-4, what="column sums")
         close(stats[32:], (pre * pre).sum(0), rtol=1e-4, atol=2e-4, what="column sums of squares")
+
+
+@pytest.mark.parametrize("case", ["sparse", "linear", "strided", "transposed"])
+def test_gathered_wgrad_bf16x3_transposing_reads(case):
+    """k_conv_wgrad_tr_b3 (bf16x3 mode, Cin / Cout >= 64: row-major LDS images + ds_read_b64_tr_b16 fragments) on ragged shapes --
+    rows not a multiple of the 32-row K step, Cout not a multiple of the 128 tile, neighbour tables with holes, stride-2 and
+    transposed dense geometry -- against float64 autograd of the same convolution."""
+    A, K, SP = _mods()
+    rng = np.random.default_rng(len(case))
+    K.set_conv_math("bf16x3")
+    try:
+        if case == "sparse":
+            rows, n_in, Cin, Cout = 1237, 1300, 64, 96
+            nbr = rng.integers(-1, n_in, size=(rows, 9)).astype(np.int32)
+            nbr[rng.random((rows, 9)) < 0.5] = -1
+            x = rng.normal(size=(n_in, Cin)).astype(np.float32)
+            go = rng.normal(size=(rows, Cout)).astype(np.float32)
+            nbr_d = torch.from_numpy(nbr).to(DEV)
+            gw = K.conv_wgrad(torch.from_numpy(x).to(DEV), torch.from_numpy(go).to(DEV), 9, K.conv_index_table(nbr_d), nbr_keepalive=nbr_d)
+            ref = np.zeros((Cout, 9, Cin))
+            for t in range(9):
+                ok = nbr[:, t] >= 0
+                ref[:, t, :] = go[ok].astype(np.float64).T @ x[nbr[ok, t]].astype(np.float64)
+            close(gw, ref, rtol=1e-4, atol=1e-4, what="sparse wgrad")
+            return
+        if case == "linear":
+            B, H, W, Cin, Cout, k, s, p, tr = 1, 1000, 1, 128, 192, 1, 1, 0, False
+        elif case == "strided":
+            B, H, W, Cin, Cout, k, s, p, tr = 2, 13, 11, 64, 160, 3, 2, 1, False
+        else:
+            B, H, W, Cin, Cout, k, s, p, tr = 2, 9, 7, 128, 64, 4, 2, 1, True
+        x = torch.from_numpy(rng.normal(size=(B, Cin, H, W))).double()
+        w = torch.from_numpy(rng.normal(size=(Cin, Cout, k, k) if tr else (Cout, Cin, k, k))).double().requires_grad_(True)
+        y = F.conv_transpose2d(x, w, None, s, p) if tr else F.conv2d(x, w, None, s, p)
+        go = torch.from_numpy(rng.normal(size=tuple(y.shape)))
+        (y * go).sum().backward()
+        spec = A.dense_conv_spec(B, H, W, k, k, s, p, transposed=tr)
+        xr = x.permute(0, 2, 3, 1).reshape(-1, Cin).float().contiguous().to(DEV)
+        gr = go.permute(0, 2, 3, 1).reshape(-1, Cout).float().contiguous().to(DEV)
+        gwk = K.conv_wgrad(xr, gr, k * k, spec.fwd_ix)                                   # kernel layout [Cout][taps][Cin]
+        ref = (w.grad.permute(1, 2, 3, 0) if tr else w.grad.permute(0, 2, 3, 1)).reshape(Cout, k * k, Cin)
+        close(gwk, ref, rtol=1e-4, atol=1e-4, what=f"{case} wgrad")
+    finally:
+        K.set_conv_math("f32")
