@@ -293,8 +293,8 @@ def main():
         other = {"conv_math": om, "value": round(args.batch * world * args.other_math_steps / odt, 3), "unit": "samples/sec",
                  "ms_per_step": round(odt / args.other_math_steps * 1e3, 3), "steps": args.other_math_steps}
     if rank_prof is not None:
-        roofline_note = (f"HIP events around every launch of this kernel in {len(hooked)} of the {args.steps} steps of the timed region (every "
-                         f"{every}th: an event pair costs the stream two marker packets); it was chosen, and the per-kernel table below measured, "
+        roofline_note = (f"HIP events around every launch of this kernel in {len(hooked)} of the {args.steps} steps of the timed region ("
+                         f"{'every step' if every == 1 else 'every second step'}: an event pair costs the stream two marker packets); it was chosen, and the per-kernel table below measured, "
                          "with events on every MFMA launch of the last warm-up step")
     else:
         roofline_note = (f"HIP events around every MFMA launch in {len(hooked)} of the {args.steps} steps of the timed region "
