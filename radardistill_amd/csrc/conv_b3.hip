@@ -409,9 +409,15 @@ int launch_conv_b3(const ConvArgs &a_in, int mode, hipStream_t st) {
     // workgroups of the 128x128 tile, the same single column tile)
     const bool wide_mid = mode == 0 && a.Cout >= 128 && !wide_off && (!big || a.Cout == 128);
     const dim3 g64128(xcd_grid(cdiv(a.out_rows, 64), cdiv(a.Cout, 128)));
+    // big layers with <= 64 output channels (the LiDAR branch's 64-channel sparse stage, 167 k rows): a 128-column tile would compute
+    // 64 columns of nothing; 128 rows x 64 columns instead
+    static const int narrow_mode = getenv("RD_TILE_NARROW") ? atoi(getenv("RD_TILE_NARROW")) : 1;
+    const bool narrow = narrow_mode == 1 && a.Cout <= 64;
+    const dim3 g12864(xcd_grid(cdiv(a.out_rows, 128), cdiv(a.Cout, 64)));
 #define RD_LAUNCH_SPEC(S)                                                                      \
     case S:                                                                                    \
         if (wide_mid) k_conv_igemm_b3<64, 128, false, false, S><<<g64128, block, 0, st>>>(a);  \
+        else if (big && narrow) k_conv_igemm_b3<128, 64, false, false, S><<<g12864, block, 0, st>>>(a); \
         else if (big) k_conv_igemm_b3<128, 128, false, false, S><<<g128, block, 0, st>>>(a);   \
         else k_conv_igemm_b3<64, 64, false, false, S><<<g64, block, 0, st>>>(a);               \
         break;
