@@ -246,6 +246,7 @@ def timing_event():
 # Optional per-launch timing hook used by bench.py for the roofline of the dominant kernel (k_conv_igemm<128,2,2,false>):
 # a list to which (start_event, end_event, algorithmic_flops) of every such launch is appended.  None = off (no overhead).
 CONV_PROFILE = None
+PROFILE_ALL = os.environ.get("RD_BENCH_SHAPES") == "all"          # diagnostic: also time the narrow (<= 64-channel) launches
 PROFILE_TAGS = None          # None: every profiled launch gets its pair of events; a set: only launches of these instantiation tags
 
 
@@ -316,7 +317,7 @@ def conv_fwd(x, weight_k, taps, bias, out_rows, Cout, ix, scale=None, shift=None
         raise RuntimeError("conv residual shape mismatch")
     out = torch.empty((out_rows, Cout), dtype=f32, device=x.device)
     # every launch of the Cout > 64, non-deform instantiations; `tile` mirrors the selection rule of rd_conv_fwd (conv.hip)
-    prof = CONV_PROFILE is not None and Cout > 64 and ix.mode != 3
+    prof = CONV_PROFILE is not None and (Cout > 64 or PROFILE_ALL) and ix.mode != 3
     tile = 128 if ((out_rows + 127) // 128) * ((Cout + 127) // 128) >= 384 else 64
     if prof:
         if taps == 1 and get_conv_math() == "bf16x3" and os.environ.get("RD_GEMM_TILE64", "1") != "0":
@@ -360,7 +361,7 @@ def conv_dgrad(grad_out, weight_k, taps, in_rows, Cin, ix_bwd, nbr_keepalive=Non
             raise RuntimeError(f"backward neighbour table shape {tuple(nbr_keepalive.shape)} != ({in_rows}, {taps})")
     gx = torch.empty((in_rows, Cin), dtype=f32, device=grad_out.device)
     tile = 128 if ((in_rows + 127) // 128) * ((Cin + 127) // 128) >= 384 else 64
-    prof = CONV_PROFILE is not None and Cin > 64 and (PROFILE_TAGS is None or tile in PROFILE_TAGS)
+    prof = CONV_PROFILE is not None and (Cin > 64 or PROFILE_ALL) and (PROFILE_TAGS is None or tile in PROFILE_TAGS)
     if prof:
         e0 = timing_event(); e1 = timing_event()
         e0.record()
