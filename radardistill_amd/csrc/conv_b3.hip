@@ -407,7 +407,12 @@ int launch_conv_b3(const ConvArgs &a_in, int mode, hipStream_t st) {
     static const bool wide_off = getenv("RD_TILE_MID") && getenv("RD_TILE_MID")[0] == '0';
     // ... and every sparse layer with exactly 128 output channels, big or not (75 k rows 128->128: 134 -> 116 us; twice the
     // workgroups of the 128x128 tile, the same single column tile)
-    const bool wide_mid = mode == 0 && a.Cout >= 128 && !wide_off && (!big || a.Cout == 128);
+    // ... and stride-2 TRANSPOSED geometry (ConvTranspose2d 4x4 s2 of the CMA decoders): an output row only has the taps of its own
+    // (oy, ox) parity class; a 64-row tile that is one output line (Wout a multiple of 64) has a single oy parity, so the tap mask
+    // drops half the taps, where a 128-row tile (two lines) keeps all sixteen
+    static const bool tline_off = getenv("RD_TILE_TLINE") && getenv("RD_TILE_TLINE")[0] == '0';
+    const bool tline = mode == 2 && a.ix.stride == 2 && a.ix.Wout % 64 == 0 && a.Cout >= 128 && !tline_off;
+    const bool wide_mid = ((mode == 0 && (!big || a.Cout == 128)) || tline) && a.Cout >= 128 && !wide_off;
     const dim3 g64128(xcd_grid(cdiv(a.out_rows, 64), cdiv(a.Cout, 128)));
     // big layers with <= 64 output channels (the LiDAR branch's 64-channel sparse stage, 167 k rows): a 128-column tile would compute
     // 64 columns of nothing; 128 rows x 64 columns instead

@@ -293,7 +293,9 @@ def _kernel_tag(ix, in_rows, out_rows, Cin, Cout, taps, in_split, tile):
         nb = out_rows // (ix.Hout * ix.Wout)
         big = nb * ((ix.Hout + 7) // 8) * ((ix.Wout + 15) // 16) * ((Cout + 127) // 128)
         return "d3_128" if big >= 384 else "d3_64"
-    if ((tile == 64 and Cout >= 128) or Cout == 128) and ix.mode == 0 and get_conv_math() == "bf16x3" and os.environ.get("RD_TILE_MID", "1") != "0":
+    if (((tile == 64 and Cout >= 128) or Cout == 128) and ix.mode == 0 or (ix.mode == 2 and ix.stride == 2 and ix.Wout % 64 == 0 and Cout >= 128
+                                                                      and os.environ.get("RD_TILE_TLINE", "1") != "0")) \
+            and get_conv_math() == "bf16x3" and os.environ.get("RD_TILE_MID", "1") != "0":
         return "64x128"          # sparse mid-size layers: 64 rows x 128 channels
     return tile
 
