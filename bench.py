@@ -355,7 +355,15 @@ def main():
             128: ("k_conv_igemm%s<128,128> (gathered implicit-GEMM conv: sparse / 1x1 / strided / transposed, forward and data gradient)" % ("_b3" if b3 else ""),
                   "k_conv_igemm_b3<128, 128" if b3 else "k_conv_igemm<128, 128"),
             64: ("k_conv_igemm%s<64,64> (gathered implicit-GEMM conv, 64x64 tiles)" % ("_b3" if b3 else ""), "k_conv_igemm_b3<64, 64" if b3 else "k_conv_igemm<64, 64"),
-            "64x128": ("k_conv_igemm_b3<64,128> (gathered implicit-GEMM conv of the mid-size sparse layers, 64-row x 128-channel tiles)", "k_conv_igemm_b3<64, 128"),
+            "64x128_table": ("k_conv_igemm_b3<64,128,..,table> (gathered implicit-GEMM conv of the sparse layers, neighbour-table geometry, 64-row x "
+                             "128-channel tiles)", "k_conv_igemm_b3<64, 128, false, false, 2"),
+            "64x128_dense": ("k_conv_igemm_b3<64,128,..,dense> (stride-2 transposed convs, one output line per tile)", "k_conv_igemm_b3<64, 128, false, false, 3"),
+            "64_table": ("k_conv_igemm_b3<64,64,..,table> (gathered implicit-GEMM conv, sparse layers, 64x64 tiles)", "k_conv_igemm_b3<64, 64, false, false, 2"),
+            "64_dense": ("k_conv_igemm_b3<64,64,..,dense> (1x1 projections, strided convs: dense geometry, 64x64 tiles)", "k_conv_igemm_b3<64, 64, false, false, 3"),
+            "128_table": ("k_conv_igemm_b3<128,128,..,table> (gathered implicit-GEMM conv, large sparse layers)", "k_conv_igemm_b3<128, 128, false, false, 2"),
+            "128_dense": ("k_conv_igemm_b3<128,128,..,dense> (large dense-geometry layers)", "k_conv_igemm_b3<128, 128, false, false, 3"),
+            "128x64_table": ("k_conv_igemm_b3<128,64,..,table> (large sparse layers with <= 64 output channels)", "k_conv_igemm_b3<128, 64, false, false, 2"),
+            "128x64_dense": ("k_conv_igemm_b3<128,64,..,dense>", "k_conv_igemm_b3<128, 64, false, false, 3"),
             "wgrad_d3": ("k_conv_wgrad_d3_b3 (weight gradient of dense stride-1 3x3 convs: 8x8-pixel grad_out tile + 10x10 input halo staged once, "
                          "all 9 taps per staged tile, ds_read_b64_tr_b16 fragments, 8 waves x (32 co x 32 ci x 9 taps))", "k_conv_wgrad_d3_b3"),
             "wgrad_b3_128": ("k_conv_wgrad_tr_b3<128> (gathered weight gradient GEMM: M = Cout tile 128, N = Cin tile 128 of one tap, K = rows; "

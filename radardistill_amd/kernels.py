@@ -296,7 +296,12 @@ def _kernel_tag(ix, in_rows, out_rows, Cin, Cout, taps, in_split, tile):
     if (((tile == 64 and Cout >= 128) or Cout == 128) and ix.mode == 0 or (ix.mode == 2 and ix.stride == 2 and ix.Wout % 64 == 0 and Cout >= 128
                                                                       and os.environ.get("RD_TILE_TLINE", "1") != "0")) \
             and get_conv_math() == "bf16x3" and os.environ.get("RD_TILE_MID", "1") != "0":
-        return "64x128"          # sparse mid-size layers: 64 rows x 128 channels
+        tile = "64x128"          # sparse mid-size layers and one-line transposed tiles: 64 rows x 128 channels
+    elif Cout <= 64 and tile == 128 and ix.mode != 3 and get_conv_math() == "bf16x3" and os.environ.get("RD_TILE_NARROW", "1") != "0":
+        tile = "128x64"
+    if get_conv_math() == "bf16x3" and Cout > 32 and ix.mode != 3:
+        # the geometry-specialised instantiations are different kernels (k_conv_igemm_b3<BM, BN, false, false, 2 | 3>): tag them apart
+        return f"{tile}_{'table' if ix.mode == 0 else 'dense'}"
     return tile
 
 
