@@ -93,11 +93,21 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
     constexpr int BUF = 2 * (BM + BN) * LDS_ROW;  // bf16 elements per buffer
     __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BUF];
 
+    // SPEC bit 3: SUB-PIXEL form of stride-2 TRANSPOSED geometry (ConvTranspose2d k 4 s 2 p 1; the data gradient of a stride-2
+    // conv).  Output pixel (2y + py, 2x + px) only meets the taps with (py + pad - ky) and (px + pad - kx) even, at the input pixels
+    // (y + (py + pad - ky) / 2, x + (px + pad - kx) / 2): a tile is BM pixels (y, x) of ONE parity class (py, px) on the half-resolution
+    // grid, its tap mask holds that class's taps only (4 of 16 for the 4x4 kernel, 1 / 2 / 2 / 4 of 9 for 3x3 -- the gathered form
+    // walks all of them for every row) and its rows are scattered to the class's output pixels in the epilogue.  The four classes of
+    // a tile position are adjacent in launch order (they read the same input rows).
+    constexpr bool SUBPIX = SPEC >= 0 && (SPEC & 8) != 0;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     int row_tile, col_tile;
-    if (!xcd_tile((a.out_rows + BM - 1) / BM, (a.Cout + BN - 1) / BN, row_tile, col_tile)) return;
-    const int m0 = row_tile * BM, n0 = col_tile * BN;
+    const int sp_h = (a.ix.Hout + 1) >> 1, sp_w = (a.ix.Wout + 1) >> 1;          // half-resolution class grid
+    const int tile_rows = SUBPIX ? a.ix.B * sp_h * sp_w : a.out_rows;          // rows the tiles enumerate
+    if (!xcd_tile((SUBPIX ? 4 : 1) * ((tile_rows + BM - 1) / BM), (a.Cout + BN - 1) / BN, row_tile, col_tile)) return;
+    const int sp_py = SUBPIX ? ((row_tile >> 1) & 1) : 0, sp_px = SUBPIX ? (row_tile & 1) : 0;
+    const int m0 = (SUBPIX ? (row_tile >> 2) : row_tile) * BM, n0 = col_tile * BN;
     const int ld_r = tid >> 3, ld_c = (tid & 7) * 4;
 
     // ---- dense geometry (modes 1 / 2): (b, oy, ox) of every tile row is worked out ONCE (three integer divisions per row, by one
@@ -112,9 +122,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
     if (dense && tid < BM) {
         const int j = m0 + tid;
         int4 q = make_int4(0, 0, 0, 0);
-        if (j < a.out_rows) {
-            const int t1 = j / a.ix.Wout;
-            q = make_int4(t1 / a.ix.Hout, t1 % a.ix.Hout, j - t1 * a.ix.Wout, 1);
+        const int gw = SUBPIX ? sp_w : a.ix.Wout, gh = SUBPIX ? sp_h : a.ix.Hout;
+        if (j < tile_rows) {
+            const int t1 = j / gw;
+            q = make_int4(t1 / gh, t1 % gh, j - t1 * gw, 1);
+            if (SUBPIX && (2 * q.y + sp_py >= a.ix.Hout || 2 * q.z + sp_px >= a.ix.Wout)) q.w = 0;          // odd map sizes: no such output pixel
         }
         s_pix[tid] = q;
     }
@@ -124,7 +136,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
     __syncthreads();
     {
         int mask = 0;
-        if (dense) {
+        if (SUBPIX) {          // block-uniform: the taps of this parity class
+            for (int t = 0; t < a.taps; ++t) {
+                const int ky = t / a.ix.KW, kx = t - ky * a.ix.KW;
+                if (((sp_py + a.ix.pad - ky) & 1) == 0 && ((sp_px + a.ix.pad - kx) & 1) == 0) mask |= 1 << t;
+            }
+        } else if (dense) {
             if (tid < BM) {
                 const int4 q = s_pix[tid];
                 if (q.w)
@@ -166,6 +183,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
     int4 sidx[DEFORM ? AP : 1];
     f32x4 sw[DEFORM ? AP : 1];
     int cur_tap = -1, tap_iter_mask = tapmask;
+    int w_tap = 0;                               // weight tap of the current step (= cur_tap except in the sub-pixel form)
 
     int next_kq = 0;                             // K chunk of the next tile to fetch (tiles are fetched strictly in order:
     auto load_tile = [&](int, Regs &R) {         // a counter instead of s % kchunks, which costs ~50 VALU instructions per step)
@@ -175,6 +193,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
         if (new_tap) {
             cur_tap = __ffs(tap_iter_mask) - 1;
             tap_iter_mask &= tap_iter_mask - 1;
+            w_tap = cur_tap;
             if constexpr (DEFORM) {
 #pragma unroll
                 for (int p = 0; p < AP; ++p) {
@@ -186,6 +205,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
                     } else {
                         sidx[p] = make_int4(-1, -1, -1, -1);
                     }
+                }
+            } else if (SUBPIX) {
+                const int ky = cur_tap / a.ix.KW, kx = cur_tap - ky * a.ix.KW;          // block-uniform; parities match by the mask
+                const int oy_off = (sp_py + a.ix.pad - ky) >> 1, ox_off = (sp_px + a.ix.pad - kx) >> 1;          // arithmetic shift: exact, may be negative
+#pragma unroll
+                for (int p = 0; p < AP; ++p) {
+                    const int4 q = s_pix[ld_r + 32 * p];
+                    const int iy = q.y + oy_off, ixx = q.z + ox_off;
+                    rows[p] = (q.w && iy >= 0 && iy < a.ix.Hin && ixx >= 0 && ixx < a.ix.Win) ? (q.x * a.ix.Hin + iy) * a.ix.Win + ixx : -1;
                 }
             } else if (dense) {
                 const int ky = cur_tap / a.ix.KW, kx = cur_tap - ky * a.ix.KW;          // block-uniform
@@ -223,14 +251,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
             for (int e = 0; e < 4; ++e) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (bt_q < BN / 4 && n < a.Cout)
-                    v = *reinterpret_cast<const f32x4 *>(a.w + ((int64_t)(kc + 4 * bt_g + e) * a.taps + cur_tap) * a.Cout + n);
+                    v = *reinterpret_cast<const f32x4 *>(a.w + ((int64_t)(kc + 4 * bt_g + e) * a.taps + w_tap) * a.Cout + n);
                 R.rbt[e] = v;
             }
         } else {
 #pragma unroll
             for (int p = 0; p < BP; ++p) {          // weight rows past Cout read the last row: those columns are never stored
                 const int n = min(n0 + ld_r + 32 * p, a.Cout - 1);
-                R.rb[p] = *reinterpret_cast<const f32x4 *>(a.w + ((int64_t)n * a.taps + cur_tap) * a.Cin + kc + ld_c);
+                R.rb[p] = *reinterpret_cast<const f32x4 *>(a.w + ((int64_t)n * a.taps + w_tap) * a.Cin + kc + ld_c);
             }
         }
     };
@@ -339,8 +367,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (row < a.out_rows && col_ok) {
+                int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                bool row_ok = row < tile_rows;
+                if (SUBPIX) {          // this class's output pixel of input pixel (b, y, x)
+                    const int4 q = s_pix[row - m0];
+                    row_ok = q.w != 0;
+                    row = (q.x * a.ix.Hout + 2 * q.y + sp_py) * a.ix.Wout + 2 * q.z + sp_px;
+                }
+                if (row_ok && col_ok) {
                     float v = acc[i][j][r] + bias;
                     csum += v;
                     csq += v * v;
@@ -413,6 +447,14 @@ int launch_conv_b3(const ConvArgs &a_in, int mode, hipStream_t st) {
     static const bool tline_off = getenv("RD_TILE_TLINE") && getenv("RD_TILE_TLINE")[0] == '0';
     const bool tline = mode == 2 && a.ix.stride == 2 && a.ix.Wout % 64 == 0 && a.Cout >= 128 && !tline_off;
     const bool wide_mid = ((mode == 0 && (!big || a.Cout == 128)) || tline) && a.Cout >= 128 && !wide_off;
+    // stride-2 transposed geometry with pre-split weights: the sub-pixel form (only the taps of an output pixel's parity class)
+    static const bool subpix_off = getenv("RD_SUBPIX") && getenv("RD_SUBPIX")[0] == '0';
+    if (!subpix_off && mode == 2 && a.ix.stride == 2 && a.w_split && !a.in_split && a.in_rows > 0 && a.taps <= 16) {
+        const int64_t class_rows = (int64_t)a.ix.B * ((a.ix.Hout + 1) / 2) * ((a.ix.Wout + 1) / 2);
+        if (a.Cout >= 128) k_conv_igemm_b3<64, 128, false, false, 11><<<dim3(xcd_grid(4 * cdiv(class_rows, 64), cdiv(a.Cout, 128))), block, 0, st>>>(a);
+        else k_conv_igemm_b3<64, 64, false, false, 11><<<dim3(xcd_grid(4 * cdiv(class_rows, 64), cdiv(a.Cout, 64))), block, 0, st>>>(a);
+        return RD_OK;
+    }
     const dim3 g64128(xcd_grid(cdiv(a.out_rows, 64), cdiv(a.Cout, 128)));
     // big layers with <= 64 output channels (the LiDAR branch's 64-channel sparse stage, 167 k rows): a 128-column tile would compute
     // 64 columns of nothing; 128 rows x 64 columns instead

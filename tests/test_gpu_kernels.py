@@ -782,3 +782,35 @@ def test_gathered_wgrad_bf16x3_transposing_reads(case):
         close(gwk, ref, rtol=1e-4, atol=1e-4, what=f"{case} wgrad")
     finally:
         K.set_conv_math("f32")
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 9, 7, 64, 128), (1, 32, 32, 256, 256), (3, 5, 6, 128, 64)])
+def test_conv_transpose_4x4_s2_subpixel_form_bf16x3(B, H, W, Cin, Cout):
+    """ConvTranspose2d(k 4, s 2, p 1) in bf16x3 mode runs in its sub-pixel form (k_conv_igemm_b3<.., 11>: one tile = input pixels of one
+    output parity class, 4 taps, rows scattered to the class's output pixels): forward incl. fused statistics, data and weight
+    gradients against torch on the CPU."""
+    A, K, SP = _mods()
+    g = np.random.default_rng(B * 100 + H)
+    x = torch.from_numpy(g.normal(size=(B, Cin, H, W)).astype(np.float32))
+    w = torch.from_numpy((g.normal(size=(Cin, Cout, 4, 4)) / np.sqrt(4 * Cin)).astype(np.float32))
+    b = torch.from_numpy(g.normal(size=Cout).astype(np.float32))
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv_transpose2d(xr, wr, br, 2, 1)
+    go = torch.from_numpy(g.normal(size=tuple(ref.shape)).astype(np.float32))
+    (ref * go).sum().backward()
+    K.set_conv_math("bf16x3")
+    try:
+        spec = A.dense_conv_spec(B, H, W, 4, 4, 2, 1, transposed=True)
+        xd = x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().to(DEV).requires_grad_(True)
+        wd, bd = torch.nn.Parameter(w.to(DEV)), torch.nn.Parameter(b.to(DEV))
+        stats = torch.zeros(2 * Cout, device=DEV)
+        A.begin_step(torch.device(DEV))
+        out = A.conv(xd, wd, bd, spec, Cout, stats)
+        ref_rows = ref.detach().permute(0, 2, 3, 1).reshape(-1, Cout)
+        close(out, ref_rows, rtol=1e-4, atol=1e-4, what="sub-pixel transposed conv")
+        close(stats[:Cout], ref_rows.sum(0), rtol=1e-4, atol=2e-4); close(stats[Cout:], (ref_rows * ref_rows).sum(0), rtol=1e-4, atol=2e-4)
+        (out * go.permute(0, 2, 3, 1).reshape(-1, Cout).to(DEV)).sum().backward()
+        close(xd.grad, xr.grad.permute(0, 2, 3, 1).reshape(-1, Cin), rtol=1e-4, atol=1e-4, what="dgrad")
+        close(wd.grad, wr.grad, rtol=1e-4, atol=2e-4, what="wgrad"); close(bd.grad, br.grad, rtol=1e-4, atol=2e-4, what="bias grad")
+    finally:
+        K.set_conv_math("f32")
