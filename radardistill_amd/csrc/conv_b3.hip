@@ -449,10 +449,16 @@ int launch_conv_b3(const ConvArgs &a_in, int mode, hipStream_t st) {
     const bool wide_mid = ((mode == 0 && (!big || a.Cout == 128)) || tline) && a.Cout >= 128 && !wide_off;
     // stride-2 transposed geometry with pre-split weights: the sub-pixel form (only the taps of an output pixel's parity class)
     static const bool subpix_off = getenv("RD_SUBPIX") && getenv("RD_SUBPIX")[0] == '0';
-    if (!subpix_off && mode == 2 && a.ix.stride == 2 && a.w_split && !a.in_split && a.in_rows > 0 && a.taps <= 16) {
+    if (!subpix_off && mode == 2 && a.ix.stride == 2 && !a.in_split && a.in_rows > 0 && a.taps <= 16) {
         const int64_t class_rows = (int64_t)a.ix.B * ((a.ix.Hout + 1) / 2) * ((a.ix.Wout + 1) / 2);
-        if (a.Cout >= 128) k_conv_igemm_b3<64, 128, false, false, 11><<<dim3(xcd_grid(4 * cdiv(class_rows, 64), cdiv(a.Cout, 128))), block, 0, st>>>(a);
-        else k_conv_igemm_b3<64, 64, false, false, 11><<<dim3(xcd_grid(4 * cdiv(class_rows, 64), cdiv(a.Cout, 64))), block, 0, st>>>(a);
+        const dim3 gw(xcd_grid(4 * cdiv(class_rows, 64), cdiv(a.Cout, 128))), gn(xcd_grid(4 * cdiv(class_rows, 64), cdiv(a.Cout, 64)));
+        if (a.w_split) {
+            if (a.Cout >= 128) k_conv_igemm_b3<64, 128, false, false, 11><<<gw, block, 0, st>>>(a);
+            else k_conv_igemm_b3<64, 64, false, false, 11><<<gn, block, 0, st>>>(a);
+        } else {          // fp32 weights split in the kernel (the zero-padded 27 -> 32 channel DCN offset convolution's data gradient)
+            if (a.Cout >= 128) k_conv_igemm_b3<64, 128, false, false, 9><<<gw, block, 0, st>>>(a);
+            else k_conv_igemm_b3<64, 64, false, false, 9><<<gn, block, 0, st>>>(a);
+        }
         return RD_OK;
     }
     const dim3 g64128(xcd_grid(cdiv(a.out_rows, 64), cdiv(a.Cout, 128)));
