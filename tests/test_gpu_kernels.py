@@ -814,3 +814,30 @@ def test_conv_transpose_4x4_s2_subpixel_form_bf16x3(B, H, W, Cin, Cout):
         close(wd.grad, wr.grad, rtol=1e-4, atol=2e-4, what="wgrad"); close(bd.grad, br.grad, rtol=1e-4, atol=2e-4, what="bias grad")
     finally:
         K.set_conv_math("f32")
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,p", [(2, 13, 11, 64, 128, 3, 1), (1, 16, 16, 128, 64, 3, 1), (2, 7, 9, 64, 64, 1, 0)])
+def test_stride2_conv_data_gradient_subpixel_form_bf16x3(B, H, W, Cin, Cout, k, p):
+    """Data gradient of a stride-2 convolution in bf16x3 mode = stride-2 transposed geometry in the sub-pixel form: odd map sizes
+    (output pixels whose parity class has no partner), 3x3 (1 / 2 / 2 / 4 taps per class) and 1x1 (one class owns the only tap)."""
+    A, K, SP = _mods()
+    g = np.random.default_rng(H * 31 + W)
+    x = torch.from_numpy(g.normal(size=(B, Cin, H, W)).astype(np.float32))
+    w = torch.from_numpy((g.normal(size=(Cout, Cin, k, k)) / np.sqrt(k * k * Cin)).astype(np.float32))
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, None, 2, p)
+    go = torch.from_numpy(g.normal(size=tuple(ref.shape)).astype(np.float32))
+    (ref * go).sum().backward()
+    K.set_conv_math("bf16x3")
+    try:
+        spec = A.dense_conv_spec(B, H, W, k, k, 2, p)
+        xd = x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().to(DEV).requires_grad_(True)
+        wd = torch.nn.Parameter(w.to(DEV))
+        A.begin_step(torch.device(DEV))
+        out = A.conv(xd, wd, None, spec, Cout)
+        close(out, ref.detach().permute(0, 2, 3, 1).reshape(-1, Cout), rtol=1e-4, atol=1e-4, what="strided conv")
+        (out * go.permute(0, 2, 3, 1).reshape(-1, Cout).to(DEV)).sum().backward()
+        close(xd.grad, xr.grad.permute(0, 2, 3, 1).reshape(-1, Cin), rtol=1e-4, atol=1e-4, what="dgrad (sub-pixel form)")
+        close(wd.grad, wr.grad, rtol=1e-4, atol=2e-4, what="wgrad")
+    finally:
+        K.set_conv_math("f32")
