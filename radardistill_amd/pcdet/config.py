@@ -41,61 +41,87 @@ class AttrDict(dict):
 EasyDict = AttrDict
 
 
+def _flatten(node, prefix):
+    """(dotted key, value) pairs in insertion order; a nested section is announced by a (prefix.key, None) header entry first."""
+    for key in node:
+        val = node[key]
+        if isinstance(val, AttrDict):
+            yield f"{prefix}.{key}", None
+            yield from _flatten(val, f"{prefix}.{key}")
+        else:
+            yield f"{prefix}.{key}", val
+
+
 def log_config_to_file(cfg, pre='cfg', logger=None):
-    for key, val in cfg.items():
-        if isinstance(cfg[key], AttrDict):
-            logger.info('----------- %s -----------' % key)
-            log_config_to_file(cfg[key], pre=pre + '.' + key, logger=logger)
-            continue
-        logger.info('%s.%s: %s' % (pre, key, val))
+    """One line per leaf (`cfg.A.B: value`) and a banner per section, in the format of the reference's training logs
+    (pcdet/config.py:7-13)."""
+    for dotted, val in _flatten(cfg, pre):
+        if val is None:
+            logger.info('----------- %s -----------' % dotted.rsplit('.', 1)[1])
+        else:
+            logger.info('%s: %s' % (dotted, val))
+
+
+def _parse_scalar(text):
+    from ast import literal_eval
+    try:
+        return literal_eval(text)
+    except Exception:
+        return text
+
+
+def _override(section, name, text):
+    """Typing rules of `--set` (pcdet/config.py:16-48): the new value must have the type of the old one, except that a section takes
+    `k1:v1,k2:v2` (each cast to the existing entry's type) and a list takes `a,b,c` (cast to the type of its first element)."""
+    old, new = section[name], _parse_scalar(text)
+    if type(new) == type(old):
+        section[name] = new
+    elif isinstance(old, AttrDict):
+        for item in new.split(','):
+            sub, sub_text = item.split(':')
+            old[sub] = type(old[sub])(sub_text)
+    elif isinstance(old, list):
+        section[name] = [type(old[0])(piece) for piece in new.split(',')]
+    else:
+        raise AssertionError('type {} does not match original type {}'.format(type(new), type(old)))
 
 
 def cfg_from_list(cfg_list, config):
-    """`--set A.B value ...` overrides with the reference's typing rules (config.py:16-48)."""
-    from ast import literal_eval
-    assert len(cfg_list) % 2 == 0
-    for k, v in zip(cfg_list[0::2], cfg_list[1::2]):
-        key_list = k.split('.')
-        d = config
-        for subkey in key_list[:-1]:
-            assert subkey in d, 'NotFoundKey: %s' % subkey
-            d = d[subkey]
-        subkey = key_list[-1]
-        assert subkey in d, 'NotFoundKey: %s' % subkey
-        try:
-            value = literal_eval(v)
-        except Exception:
-            value = v
-        if type(value) != type(d[subkey]) and isinstance(d[subkey], AttrDict):
-            for src in value.split(','):
-                cur_key, cur_val = src.split(':')
-                d[subkey][cur_key] = type(d[subkey][cur_key])(cur_val)
-        elif type(value) != type(d[subkey]) and isinstance(d[subkey], list):
-            val_list = value.split(',')
-            d[subkey] = [type(d[subkey][0])(x) for x in val_list]
-        else:
-            assert type(value) == type(d[subkey]), 'type {} does not match original type {}'.format(type(value), type(d[subkey]))
-            d[subkey] = value
+    """`--set A.B value C.D value ...`: every key must already exist."""
+    if len(cfg_list) % 2:
+        raise AssertionError('--set takes KEY VALUE pairs')
+    pairs = zip(cfg_list[::2], cfg_list[1::2])
+    for dotted, text in pairs:
+        *path, leaf = dotted.split('.')
+        section = config
+        for name in path:
+            if name not in section:
+                raise AssertionError('NotFoundKey: %s' % name)
+            section = section[name]
+        if leaf not in section:
+            raise AssertionError('NotFoundKey: %s' % leaf)
+        _override(section, leaf, text)
 
 
 def merge_new_config(config, new_config):
-    if '_BASE_CONFIG_' in new_config:
-        with open(new_config['_BASE_CONFIG_'], 'r') as f:       # resolved relative to the CWD, like the reference
+    """Recursive merge of a loaded YAML mapping into `config`; `_BASE_CONFIG_: path` (resolved against the working directory, as in
+    the reference, pcdet/config.py:51-67) is loaded into the same level first."""
+    base = new_config.get('_BASE_CONFIG_')
+    if base is not None:
+        with open(base, 'r') as f:
             config.update(AttrDict(yaml.safe_load(f)))
-    for key, val in new_config.items():
-        if not isinstance(val, dict):
+    for key in new_config:
+        val = new_config[key]
+        if isinstance(val, dict):
+            merge_new_config(config.setdefault(key, AttrDict()), val)
+        else:
             config[key] = val
-            continue
-        if key not in config:
-            config[key] = AttrDict()
-        merge_new_config(config[key], val)
     return config
 
 
 def cfg_from_yaml_file(cfg_file, config):
     with open(cfg_file, 'r') as f:
-        new_config = yaml.safe_load(f)
-    merge_new_config(config=config, new_config=new_config)
+        merge_new_config(config=config, new_config=yaml.safe_load(f))
     return config
 
 

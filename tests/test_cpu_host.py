@@ -293,3 +293,30 @@ def test_centernet_helpers_vs_golden_pinned_oracle(golden_dir):
             assert torch.equal(out[bidx]["pred_labels"].long(), labels)
             np.testing.assert_allclose(out[bidx]["pred_boxes"].numpy(), boxes.numpy(), rtol=1e-6, atol=1e-6)
             np.testing.assert_allclose(out[bidx]["pred_scores"].numpy(), scores.numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_config_set_overrides_and_logging():
+    """pcdet/config.py:7-48 semantics: `--set` typing rules (scalar of the same type, `k:v,k:v` into a section, `a,b` into a list,
+    unknown keys and type changes rejected) and the log format."""
+    from radardistill_amd.pcdet.config import AttrDict, cfg_from_list, log_config_to_file
+    c = AttrDict({"A": {"LR": 0.003, "STEPS": [35, 45], "SUB": {"X": 1, "NAME": "n"}}, "A2": {"A": 5}, "FLAG": True})
+    cfg_from_list(["A.LR", "0.01", "A.STEPS", "10,20,30", "A.SUB", "X:7,NAME:q", "A2.A", "6", "FLAG", "False"], c)
+    assert c.A.LR == 0.01 and c.A.STEPS == [10, 20, 30] and c.A.SUB.X == 7 and c.A.SUB.NAME == "q" and c.A2.A == 6 and c.FLAG is False
+    with pytest.raises(AssertionError):
+        cfg_from_list(["A.MISSING", "1"], c)
+    with pytest.raises(AssertionError):
+        cfg_from_list(["A.LR", "'text'"], c)
+    with pytest.raises(AssertionError):
+        cfg_from_list(["A.LR"], c)
+
+    class Log:
+        def __init__(self):
+            self.lines = []
+
+        def info(self, s):
+            self.lines.append(s)
+
+    lg = Log()
+    log_config_to_file(c, logger=lg)
+    assert lg.lines[0] == "----------- A -----------" and "cfg.A.LR: 0.01" in lg.lines and "cfg.A.SUB.X: 7" in lg.lines and "cfg.FLAG: False" in lg.lines
+    assert "----------- SUB -----------" in lg.lines
