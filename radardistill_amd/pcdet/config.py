@@ -77,11 +77,11 @@ def _override(section, name, text):
     if type(new) == type(old):
         section[name] = new
     elif isinstance(old, AttrDict):
-        for item in new.split(','):
+        for item in text.split(','):
             sub, sub_text = item.split(':')
             old[sub] = type(old[sub])(sub_text)
-    elif isinstance(old, list):
-        section[name] = [type(old[0])(piece) for piece in new.split(',')]
+    elif isinstance(old, list):          # split the TEXT: `10,20,30` literal-evals to a tuple (on which the reference's value.split fails)
+        section[name] = [type(old[0])(piece) for piece in text.split(',')]
     else:
         raise AssertionError('type {} does not match original type {}'.format(type(new), type(old)))
 
