@@ -327,11 +327,16 @@ def _queue_wgrad_join(device, main):
     def _join():
         _WGRAD_JOIN_QUEUED[0] = False
         main.wait_stream(_WGRAD_STREAMS[device])
+        _PG_KEEP.clear()          # the main stream is now ordered after everything the side stream read
 
     torch.autograd.Variable._execution_engine.queue_callback(_join)
 
 
 _PG_STATE = {}          # device -> (main stream of this backward pass, reusable event)
+# Tensors the side stream reads are HELD until the join instead of being marked with Tensor.record_stream: a recorded block costs the
+# caching allocator an event record when it is freed and an event query per later allocation (~200 tensors per step: 0.5 ms of HIP
+# runtime calls); with 288 GB of HBM the few GB of gradients that stay alive until the end of the backward pass are free.
+_PG_KEEP = []
 _set_raw_stream = getattr(torch._C, "_cuda_setStream", None)
 
 
@@ -349,10 +354,62 @@ def _side_ok(param):
     the main stream.  A non-leaf weight (the concatenated CenterHead branches) names its leaves in `_rd_leaves`."""
     if param is None:
         return True
-    if param.is_leaf:
-        return param.grad is None
     leaves = getattr(param, "_rd_leaves", None)
-    return leaves is not None and all(p.grad is None for p in leaves)
+    if leaves is not None:
+        return (not param.is_leaf or param.grad is None) and all(p.grad is None for p in leaves)
+    return param.is_leaf and param.grad is None
+
+
+# A parameter gradient that reaches its leaves without autograd's AccumulateGrad nodes (ConcatLeaves below) still has to reach whoever
+# listens for "this parameter's gradient is complete" (FlatAdam's bucketed all-reduce): listeners are called with the leaf.
+GRAD_LISTENERS = []
+
+
+def deliver_grad(leaf, g):
+    """leaf.grad = g (or += g when the leaf already holds a gradient), then tell the listeners."""
+    if leaf.grad is None:
+        leaf.grad = g
+    else:
+        leaf.grad = leaf.grad + g
+    for cb in GRAD_LISTENERS:
+        cb(leaf)
+
+
+class ConcatLeaves:
+    """Several leaf parameters that one kernel consumes concatenated along dim 0 (the 42 CenterHead branches: weights, biases,
+    BatchNorm affines), kept as ONE persistent leaf tensor: refresh() copies the current parameter values in (one launch), the
+    convolution / BatchNorm Functions see a single leaf (one AccumulateGrad node, the persistent operand cache applies), and when its
+    gradient has been accumulated a hook hands dim-0 VIEWS of it to the real parameters.  Before: torch.cat in the graph, i.e. a
+    CatBackward (42 narrows) + 42 AccumulateGrad nodes per concatenated tensor and step -- 1.2 ms of host time per step for the head."""
+
+    def __init__(self, leaves):
+        self.leaves = list(leaves)
+        self.sizes = [int(p.shape[0]) for p in self.leaves]
+        with torch.no_grad():
+            self.cat = torch.cat([p.detach() for p in self.leaves], 0).contiguous()
+        self.cat.requires_grad_(True)
+        self.cat._rd_leaves = self.leaves
+        self.cat.register_post_accumulate_grad_hook(self._distribute)
+        self._sig = None
+
+    def valid(self):
+        c = self.cat
+        return all(p.requires_grad and p.device == c.device and p.dtype == c.dtype for p in self.leaves)
+
+    def refresh(self):
+        """Copy the parameters' current values into the concatenated leaf when any of them changed -> the leaf."""
+        self.cat.grad = None          # last pass's gradient lives on in the leaves' views
+        sig = (tuple(p._version for p in self.leaves), _WEIGHTS_EPOCH[0], self.leaves[0].data_ptr())
+        if sig != self._sig:
+            with torch.no_grad():
+                torch.cat([p.detach() for p in self.leaves], 0, out=self.cat)
+            self._sig = sig
+        return self.cat
+
+    def _distribute(self, cat):
+        # cat.grad itself stays until the next refresh(): a deferred weight re-layout finds its destination through it
+        for leaf, v in zip(self.leaves, cat.grad.split(self.sizes)):
+            deliver_grad(leaf, v)
 
 
 def param_grad_stream(fn, *inputs, param=None):
@@ -382,9 +439,7 @@ def param_grad_stream(fn, *inputs, param=None):
             out = out.contiguous()            # a strided gradient would be CLONED by AccumulateGrad -- on the main stream, unordered
     finally:
         _set_stream(main)
-    for t in inputs:
-        if t is not None:
-            t.record_stream(side)
+    _PG_KEEP.append(inputs)
     return out
 
 
@@ -666,19 +721,19 @@ class _BNActFn(torch.autograd.Function):
             stats = synced_stats(stats, C, rows, group)
         elif stats is None:
             stats = K.bn_stats(x)
-        y, mean, rstd, scale, shift = K.bn_train_fwd(x, stats, gamma, beta, eps, momentum, running_mean, running_var, residual, act,
-                                                     sync=group is not None)
+        y, side = K.bn_train_fwd(x, stats, gamma, beta, eps, momentum, running_mean, running_var, residual, act, sync=group is not None)
         ctx.act, ctx.has_res, ctx.group = act, residual is not None, group
         ctx.count = stats[2 * C:] if group is not None else None          # a slice of the per-step arena (shared version counter): kept as an attribute
-        ctx.save_for_backward(x, y, gamma, mean, rstd, scale, shift)
+        ctx.save_for_backward(x, y, gamma, side)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, y, gamma, mean, rstd, scale, shift = ctx.saved_tensors
+        x, y, gamma, side = ctx.saved_tensors
         sync = (_group_sum(ctx.group), ctx.count) if ctx.group is not None else None
-        gx, gres, gg, gb = K.bn_bwd(x, y, gy.contiguous(), gamma, mean, rstd, scale, shift, ctx.act, ctx.has_res, sync=sync)
+        gx, gres, gg, gb = K.bn_bwd(x, y, gy.contiguous(), gamma, side, ctx.act, ctx.has_res, sync=sync)
         if _DEBUG and ctx.act in (0, 1) and sync is None:
+            mean, rstd = side[0], side[1]
             g = gy.double() * ((y > 0).double() if ctx.act == 1 else 1.0)
             xh = (x.double() - mean.double()) * rstd.double()
             n = x.shape[0]
@@ -727,17 +782,17 @@ class _ConvBNActFn(torch.autograd.Function):
         ctx.bias_feeds_bn = True
         if sync:
             synced_stats(ext, Cout, raw.shape[0], group)
-        y, mean, rstd, scale, shift = K.bn_train_fwd(raw, ext, gamma, beta, eps, momentum, running_mean, running_var, residual, act, sync=sync)
+        y, side = K.bn_train_fwd(raw, ext, gamma, beta, eps, momentum, running_mean, running_var, residual, act, sync=sync)
         ctx.act, ctx.has_res, ctx.group = act, residual is not None, group
         ctx.count = ext[2 * Cout:] if sync else None
-        ctx.save_for_backward(x, weight, raw, y, gamma, mean, rstd, scale, shift)
+        ctx.save_for_backward(x, weight, raw, y, gamma, side)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight, raw, y, gamma, mean, rstd, scale, shift = ctx.saved_tensors
+        x, weight, raw, y, gamma, side = ctx.saved_tensors
         sync = (_group_sum(ctx.group), ctx.count) if ctx.group is not None else None
-        graw, gres, gg, gb_bn = K.bn_bwd(raw, y, gy.contiguous(), gamma, mean, rstd, scale, shift, ctx.act, ctx.has_res, sync=sync)
+        graw, gres, gg, gb_bn = K.bn_bwd(raw, y, gy.contiguous(), gamma, side, ctx.act, ctx.has_res, sync=sync)
         n = ctx.needs_input_grad
         gx, gw, gb = _ConvFn.backward_impl(ctx, x, weight, graw, n[0], n[1], n[2])
         return gx, gw, gb, None, None, gg, gb_bn, gres, None, None, None, None, None, None

@@ -476,7 +476,8 @@ BN_PROFILE = None
 
 
 def bn_train_fwd(x, stats, gamma, beta, eps, momentum, running_mean, running_var, residual, act, sync=False):
-    """finalize + affine + residual + activation in one launch -> y, (mean, rstd, scale, shift) for the backward pass.
+    """finalize + affine + residual + activation in one launch -> y, side (4, C) = [mean | rstd | scale | shift] for the backward
+    pass (one tensor: four row views cost four tensor objects per layer and step).
     sync: stats holds 2C + 1 values (sums and the row count) already summed over the process group (SyncBatchNorm)."""
     _chk(x, f32, "bn input", 2)
     rows, C = x.shape
@@ -494,12 +495,13 @@ def bn_train_fwd(x, stats, gamma, beta, eps, momentum, running_mean, running_var
         e0 = timing_event(); e1 = timing_event()
         e0.record()
     fn = native.lib().rd_bn_train_fwd_sync if sync else native.lib().rd_bn_train_fwd
+    sp = side.data_ptr()
     check(fn(_p(x), rows, C, _p(stats), _p(gamma), _p(beta), eps, momentum, _p(running_mean), _p(running_var),
-             _p(residual), act, _p(y), _p(side[0]), _p(side[1]), _p(side[2]), _p(side[3]), _stream()), "rd_bn_train_fwd")
+             _p(residual), act, _p(y), sp, sp + 4 * C, sp + 8 * C, sp + 12 * C, _stream()), "rd_bn_train_fwd")
     if prof:
         e1.record()
         BN_PROFILE.append((e0, e1, float(rows) * C * 4 * (3 if residual is not None else 2), (rows, C)))   # read x (+ residual), write y
-    return y, side[0], side[1], side[2], side[3]
+    return y, side
 
 
 def bn_finalize(stats, rows, C, gamma, beta, eps, momentum, running_mean, running_var, sync=False):
@@ -530,13 +532,17 @@ def affine_act(x, scale, shift, residual, act):
     return y
 
 
-def bn_bwd(x, y, grad_y, gamma, mean, rstd, scale, shift, act, has_residual, sync=None):
-    """sync = (allreduce, count_dev): SyncBatchNorm -- `allreduce(t)` sums a device tensor over the process group in place,
+def bn_bwd(x, y, grad_y, gamma, side, act, has_residual, sync=None):
+    """side: (4, C) [mean | rstd | scale | shift] of bn_train_fwd.  sync = (allreduce, count_dev): SyncBatchNorm -- `allreduce(t)` sums a device tensor over the process group in place,
     count_dev is the group-wide row count; the returned parameter gradients are this rank's own sums (torch semantics)."""
     _chk(x, f32, "x", 2); _chk(grad_y, f32, "grad_y", 2)
     rows, C = x.shape
     if grad_y.shape != x.shape or (y is not None and y.shape != x.shape):
         raise RuntimeError("bn_bwd: shape mismatch")
+    if _chk(side, f32, "bn side", 2).shape != (4, C):
+        raise RuntimeError("bn_bwd: side must be the (4, C) tensor of bn_train_fwd")
+    mean = side.data_ptr()
+    rstd, scale, shift = mean + 4 * C, mean + 8 * C, mean + 12 * C
     gx = torch.empty_like(x)
     gres = torch.empty_like(x) if has_residual else None
     from . import autograd as _A
@@ -546,15 +552,15 @@ def bn_bwd(x, y, grad_y, gamma, mean, rstd, scale, shift, act, has_residual, syn
         y = None                                     # ReLU mask re-derived from x*scale + shift: one tensor less to stream
     if sync is not None:
         allreduce, count_dev = sync
-        check(native.lib().rd_bn_bwd_reduce(_p(x), _p(y), _p(grad_y), rows, C, _p(mean), _p(rstd), _p(scale), _p(shift), act, int(has_residual),
+        check(native.lib().rd_bn_bwd_reduce(_p(x), _p(y), _p(grad_y), rows, C, mean, rstd, scale, shift, act, int(has_residual),
                                             _p(gg), _p(gb), _stream()), "rd_bn_bwd_reduce")
         tot = g2.clone()
         allreduce(tot)
-        check(native.lib().rd_bn_bwd_apply(_p(x), _p(y), _p(grad_y), rows, C, _p(gamma), _p(mean), _p(rstd), _p(scale), _p(shift), act,
+        check(native.lib().rd_bn_bwd_apply(_p(x), _p(y), _p(grad_y), rows, C, _p(gamma), mean, rstd, scale, shift, act,
                                            int(has_residual), _p(tot[:C]), _p(tot[C:]), _p(count_dev), _p(gx), _p(gres), _stream()),
               "rd_bn_bwd_apply")
         return gx, gres, gg, gb
-    check(native.lib().rd_bn_bwd(_p(x), _p(y), _p(grad_y), rows, C, _p(gamma), _p(mean), _p(rstd), _p(scale), _p(shift), act,
+    check(native.lib().rd_bn_bwd(_p(x), _p(y), _p(grad_y), rows, C, _p(gamma), mean, rstd, scale, shift, act,
                                  int(has_residual), _p(gx), _p(gres), _p(gg), _p(gb), _stream()), "rd_bn_bwd")
     return gx, gres, gg, gb
 

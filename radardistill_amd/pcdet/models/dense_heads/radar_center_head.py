@@ -125,6 +125,22 @@ class _BranchBatch:
             self.frozen_cache = (ver, w1k, b1, scale, shift, w2, b2)
         return self.frozen_cache[1:]
 
+    def _train_store(self):
+        """Training: the branches' parameters as persistent concatenated leaves (autograd.ConcatLeaves), built once; None when a
+        branch parameter is frozen (the per-branch path handles mixed cases)."""
+        st = getattr(self, '_store', None)
+        first = self.branches[0]
+        if st is not None and st['w1'].leaves[0] is first[2].weight and st['w1'].cat.device == first[2].weight.device:
+            return st if st['ok'] else None
+        groups = {'w1': [b[2].weight for b in self.branches], 'gamma': [b[3].weight for b in self.branches],
+                  'beta': [b[3].bias for b in self.branches], 'w2': [b[4].weight for b in self.branches], 'b2': [b[4].bias for b in self.branches]}
+        if first[2].bias is not None:
+            groups['b1'] = [b[2].bias for b in self.branches]
+        st = {k: A.ConcatLeaves(v) for k, v in groups.items()}
+        st['ok'] = all(c.valid() for c in st.values())
+        self._store = st
+        return st if st['ok'] else None
+
     def run(self, x):
         """x = (rows (B*H*W, 64), B, H, W) -> (out (B*H*W, NO), per-head dicts of NCHW views)."""
         from radardistill_amd import kernels as K
@@ -145,15 +161,25 @@ class _BranchBatch:
                            w_split=K.get_conv_math() == "bf16x3")
             out = K.nconv_fwd(y, w2, b2, B, H, W, self.tab)
         elif training:
-            w1 = torch.cat([b[2].weight for b in self.branches], 0)
-            b1 = torch.cat([b[2].bias for b in self.branches]) if self.branches[0][2].bias is not None else None
-            w1._rd_leaves = [b[2].weight for b in self.branches]          # who receives the gradient (autograd.param_grad_stream)
-            if b1 is not None:
-                b1._rd_leaves = [b[2].bias for b in self.branches]
+            # parameters of the 42 branches concatenated: persistent leaves whose gradients are handed to the branch parameters as
+            # views (autograd.ConcatLeaves); under HIP-graph capture (torch.autograd.grad over the module's own parameters) or with
+            # partly frozen branches: torch.cat inside the graph
+            st = None if A.CAPTURING[0] else self._train_store()
+
+            def cat(key, mod, name):
+                if st is not None:
+                    return st[key].refresh()
+                leaves = [getattr(b[mod], name) for b in self.branches]
+                t = torch.cat(leaves, 0)
+                t._rd_leaves = leaves          # who receives the gradient (autograd.param_grad_stream)
+                return t
+
+            w1 = cat('w1', 2, 'weight')
+            b1 = cat('b1', 2, 'bias') if self.branches[0][2].bias is not None else None
             stats = A.zeros_stats(2 * C1, rows.device)
             raw = A.conv(rows, w1, b1, spec, C1, stats, bias_feeds_bn=True)
-            gamma = torch.cat([bn.weight for bn in bns])
-            beta = torch.cat([bn.bias for bn in bns])
+            gamma = cat('gamma', 3, 'weight')
+            beta = cat('beta', 3, 'bias')
             with torch.no_grad():
                 rm = torch.cat([bn.running_mean for bn in bns])
                 rv = torch.cat([bn.running_var for bn in bns])
@@ -161,11 +187,7 @@ class _BranchBatch:
             with torch.no_grad():
                 torch._foreach_copy_([bn.running_mean for bn in bns], list(rm.split(64)))
                 torch._foreach_copy_([bn.running_var for bn in bns], list(rv.split(64)))
-            w2 = torch.cat([b[4].weight for b in self.branches], 0)
-            b2 = torch.cat([b[4].bias for b in self.branches])
-            w2._rd_leaves = [b[4].weight for b in self.branches]
-            b2._rd_leaves = [b[4].bias for b in self.branches]
-            out = A.nconv(y, w2, b2, B, H, W, self.tab)
+            out = A.nconv(y, cat('w2', 4, 'weight'), cat('b2', 4, 'bias'), B, H, W, self.tab)
         else:
             return None                       # eval-mode BatchNorm with gradients: rare, the per-branch path handles it
         o4 = out.view(B, H, W, self.no)

@@ -10,6 +10,7 @@ multi-tensor HIP launches (optim.hip), the clip coefficient never visits the hos
 """
 import ctypes
 import math
+import weakref
 
 import numpy as np
 import torch
@@ -126,6 +127,18 @@ class FusedAdamOneCycle:
             A.DEFER_LAYOUT[0] = False          # a bucket is packed mid-backward: every gradient must be complete when its hook fires
             for i, p in enumerate(self.params):
                 p.register_post_accumulate_grad_hook(lambda _p, i=i: self._grad_ready(i))
+            # gradients delivered outside autograd's AccumulateGrad (autograd.ConcatLeaves) announce themselves here
+            index = {id(p): i for i, p in enumerate(self.params)}
+            me = weakref.ref(self)
+
+            def _delivered(leaf):
+                opt, i = me(), index.get(id(leaf))
+                if opt is not None and i is not None and opt.params[i] is leaf:
+                    opt._grad_ready(i)
+
+            A.GRAD_LISTENERS[:] = [cb for cb in A.GRAD_LISTENERS if getattr(cb, '_owner', lambda: None)() is not None]
+            _delivered._owner = me
+            A.GRAD_LISTENERS.append(_delivered)
 
     def _grad_ready(self, i):
         b = self.buckets.ready(i)
