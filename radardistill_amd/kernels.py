@@ -317,16 +317,22 @@ def conv_fwd(x, weight_k, taps, bias, out_rows, Cout, ix, scale=None, shift=None
     if ix.mode == 0 and nbr_keepalive is not None:
         if nbr_keepalive.shape != (out_rows, taps) or nbr_keepalive.dtype != i32 or not nbr_keepalive.is_contiguous():
             raise RuntimeError(f"neighbour table shape {tuple(nbr_keepalive.shape)} != ({out_rows}, {taps})")
-    for t, nm, n in ((bias, "bias", Cout), (scale, "scale", Cout), (shift, "shift", Cout), (stats, "stats", 2 * Cout)):
-        if t is not None and (_chk(t, f32, nm).numel() != n):
-            raise RuntimeError(f"conv {nm}: {t.numel()} elements, expected {n}")
+    # (this wrapper runs ~165 times per step: the optional operands are checked inline, not through a loop over tuples)
+    if bias is not None and _chk(bias, f32, "bias").numel() != Cout:
+        raise RuntimeError(f"conv bias: {bias.numel()} elements, expected {Cout}")
+    if scale is not None and _chk(scale, f32, "scale").numel() != Cout:
+        raise RuntimeError(f"conv scale: {scale.numel()} elements, expected {Cout}")
+    if shift is not None and _chk(shift, f32, "shift").numel() != Cout:
+        raise RuntimeError(f"conv shift: {shift.numel()} elements, expected {Cout}")
+    if stats is not None and _chk(stats, f32, "stats").numel() != 2 * Cout:
+        raise RuntimeError(f"conv stats: {stats.numel()} elements, expected {2 * Cout}")
     if residual is not None and (_chk(residual, f32, "residual").shape != (out_rows, Cout)):
         raise RuntimeError("conv residual shape mismatch")
     out = torch.empty((out_rows, Cout), dtype=f32, device=x.device)
     # every launch of the Cout > 64, non-deform instantiations; `tile` mirrors the selection rule of rd_conv_fwd (conv.hip)
     prof = CONV_PROFILE is not None and (Cout > 64 or PROFILE_ALL) and ix.mode != 3
-    tile = 128 if ((out_rows + 127) // 128) * ((Cout + 127) // 128) >= 384 else 64
     if prof:
+        tile = 128 if ((out_rows + 127) // 128) * ((Cout + 127) // 128) >= 384 else 64
         if taps == 1 and get_conv_math() == "bf16x3" and os.environ.get("RD_GEMM_TILE64", "1") != "0":
             tile = 64          # 1-tap layers: 64x64 tiles whatever the size (launch_conv_b3)
         tile = _kernel_tag(ix, in_rows, out_rows, Cin, Cout, taps, in_split, tile)
@@ -485,9 +491,14 @@ def bn_train_fwd(x, stats, gamma, beta, eps, momentum, running_mean, running_var
         raise RuntimeError("bn_train_fwd: stats must hold 2*C sums (+ the row count when synchronised)")
     if residual is not None and _chk(residual, f32, "residual", 2).shape != x.shape:
         raise RuntimeError("bn_train_fwd: residual shape mismatch")
-    for t, nm in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
-        if t is not None and _chk(t, f32, nm).numel() != C:
-            raise RuntimeError(f"bn_train_fwd: {nm} must have {C} elements")
+    if gamma is not None and _chk(gamma, f32, "gamma").numel() != C:
+        raise RuntimeError(f"bn_train_fwd: gamma must have {C} elements")
+    if beta is not None and _chk(beta, f32, "beta").numel() != C:
+        raise RuntimeError(f"bn_train_fwd: beta must have {C} elements")
+    if running_mean is not None and _chk(running_mean, f32, "running_mean").numel() != C:
+        raise RuntimeError(f"bn_train_fwd: running_mean must have {C} elements")
+    if running_var is not None and _chk(running_var, f32, "running_var").numel() != C:
+        raise RuntimeError(f"bn_train_fwd: running_var must have {C} elements")
     side = torch.empty((4, C), dtype=f32, device=x.device)
     y = torch.empty_like(x)
     prof = BN_PROFILE is not None and rows * C >= 2_000_000          # the bench only uses launches that move >= 16 MB
