@@ -304,6 +304,61 @@ def test_center_head_batched_branches_equal_per_branch_path(training):
             close(sa[k], sb[k], what=k)
 
 
+def test_center_head_concatenated_leaves_accumulate_and_follow_the_parameters():
+    """autograd.ConcatLeaves behind the batched CenterHead branches: (a) a second backward pass without zero_grad ADDS to the branch
+    parameters' gradients (delivered as views, outside AccumulateGrad), (b) after the parameters change in place the concatenated
+    leaves are refreshed -- predictions equal the per-branch path again, (c) with one branch parameter frozen the plan falls back to
+    torch.cat inside the graph and the frozen parameter gets no gradient."""
+    import copy
+    from radardistill_amd import autograd as A
+    g = np.random.default_rng(32)
+    feat = torch.from_numpy(g.normal(0, 1, size=(2, 256, 16, 16)).astype(np.float32))
+    batch = make_batch(batch_size=2, n_lidar=16, n_radar=16, n_boxes=12, grid=128, seed=4)
+    gt = torch.from_numpy(batch["gt_boxes"]).to(DEV)
+    m = _head(seed=16)
+    m.train()
+
+    def step(mod):
+        mod({"radar_spatial_features_2d": _cl(feat), "gt_boxes": gt, "gt_boxes_host": batch["gt_boxes"], "batch_size": 2})
+        loss, _ = mod.get_loss()
+        loss.sum().backward()
+        A.end_forward()
+        return loss.detach()
+
+    step(m)
+    assert m._branch_plan[0]._store['ok']
+    g1 = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    step(m)                                           # no zero_grad: the second pass accumulates
+    for k, p in m.named_parameters():
+        close(p.grad, 2 * g1[k], rtol=2e-3, atol=2e-4 * float(g1[k].abs().max()) + 1e-7, what=f"accumulated grad {k}")
+    # (b) in-place parameter update (what torch optimizers do), then compare with the per-branch path of a copy
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.05)
+    ref = _head(seed=16)
+    ref.load_state_dict(m.state_dict())
+    ref.train()
+    ref.model_cfg = copy.deepcopy(ref.model_cfg); ref.model_cfg["BATCH_BRANCHES"] = False
+    for mod in (m, ref):
+        for p in mod.parameters():
+            p.grad = None
+    la, lb = step(m), step(ref)
+    close(la, lb, rtol=1e-4)
+    gm, gr = dict(m.named_parameters()), dict(ref.named_parameters())
+    for k in gr:
+        close(gm[k].grad, gr[k].grad, rtol=2e-3, atol=2e-4, what=f"grad after update {k}")
+    # (c) one frozen branch parameter: fallback to torch.cat in the graph
+    frozen = m.heads_list[0].center[1].weight
+    frozen.requires_grad_(False)
+    m._branch_plan[0]._store = None
+    for p in m.parameters():
+        p.grad = None
+    step(m)
+    assert m._branch_plan[0]._store['ok'] is False
+    assert frozen.grad is None
+    assert all(p.grad is not None for p in m.parameters() if p.requires_grad)
+
+
 def test_conv5_golden(golden_dir):
     from functools import partial
     from radardistill_amd.pcdet.models.backbones_3d.spconv_backbone_2d import BasicBlock, post_act_block_dense
