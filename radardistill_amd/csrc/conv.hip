@@ -248,6 +248,7 @@ static int validate_index(const rd_conv_index *ix, int taps, int in_rows, int ou
 static int g_conv_math = 0;
 int launch_conv_b3(const ConvArgs &a, int mode, hipStream_t st);
 bool launch_conv_small_b3(const ConvArgs &a, hipStream_t st);
+bool launch_conv_narrow_b3(const ConvArgs &a, hipStream_t st);
 int launch_dgrad_b3(const ConvArgs &a, hipStream_t st);
 int launch_wgrad_b3(const float *in, int in_rows, int Cin, const float *go, int out_rows, int Cout, int taps, const rd_conv_index *idx, float *gw,
                     int rows_per_block, int64_t chunks, int tiles, int cin_tile, int in_split, int go_split, hipStream_t st);
@@ -306,6 +307,7 @@ static int conv_fwd_impl(const float *in, int in_rows, int Cin, const float *wei
         return check_launch("rd_conv_fwd(bf16x3)");
     }
     if (g_conv_math == 1 && launch_conv_small_b3(a, st)) return check_launch("rd_conv_fwd(bf16x3, 32-channel sparse)");
+    if (g_conv_math == 1 && launch_conv_narrow_b3(a, st)) return check_launch("rd_conv_fwd(bf16x3, narrow output, split K)");
     // Tile choice: 128x128 when that already gives every CU two workgroups (512 resident blocks), otherwise 64x64 tiles
     // (4x the workgroups; operands are L2-resident at these sizes, so the extra re-reads stay on chip).
     const int64_t big_blocks = cdiv(out_rows, 128) * cdiv(Cout, 128);

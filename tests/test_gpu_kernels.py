@@ -840,4 +840,39 @@ def test_stride2_conv_data_gradient_subpixel_form_bf16x3(B, H, W, Cin, Cout, k, 
         close(xd.grad, xr.grad.permute(0, 2, 3, 1).reshape(-1, Cin), rtol=1e-4, atol=1e-4, what="dgrad (sub-pixel form)")
         close(wd.grad, wr.grad, rtol=1e-4, atol=2e-4, what="wgrad")
     finally:
+        K.set_conv_math("f32")@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride", [(2, 20, 24, 256, 27, 2), (1, 13, 11, 96, 27, 2), (2, 9, 16, 64, 5, 1), (1, 32, 32, 256, 32, 2)])
+def test_narrow_output_conv_split_k_bf16x3(B, H, W, Cin, Cout, stride):
+    """conv_small.hip k_conv_narrow_b3 (the CMA blocks' 256 -> 27 DCNv2 offset / mask convolution: one wavefront per 32 output pixels,
+    contraction split over 32-channel slices combined with atomics into a zero-filled output, bias added by slice 0): forward through
+    the autograd layer against torch on the CPU -- stride 2 and 1, ragged maps (rows not a multiple of 32 / 128), 3 and 8 slices --
+    plus the gradients of the same layer (unchanged kernels) and the deterministic mode, which keeps the tiled kernel."""
+    A, K, SP = _mods()
+    g = np.random.default_rng(B * 1000 + H * 10 + Cin)
+    x = torch.from_numpy(g.normal(size=(B, Cin, H, W)).astype(np.float32))
+    w = torch.from_numpy((g.normal(size=(Cout, Cin, 3, 3)) / np.sqrt(9 * Cin)).astype(np.float32))
+    b = torch.from_numpy(g.normal(size=Cout).astype(np.float32))
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv2d(xr.double(), wr.double(), br.double(), stride=stride, padding=1)
+    go = torch.from_numpy(g.normal(size=tuple(ref.shape)).astype(np.float32))
+    (ref * go.double()).sum().backward()
+    ref_rows = ref.detach().permute(0, 2, 3, 1).reshape(-1, Cout)
+    K.set_conv_math("bf16x3")
+    try:
+        spec = A.dense_conv_spec(B, H, W, 3, 3, stride, 1)
+        for det in (False, True):
+            K.set_deterministic(det)
+            xd = x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().to(DEV).requires_grad_(True)
+            wd, bd = torch.nn.Parameter(w.to(DEV)), torch.nn.Parameter(b.to(DEV))
+            A.begin_step(torch.device(DEV))
+            out = A.conv(xd, wd, bd, spec, Cout, None)
+            close(out, ref_rows, rtol=1e-4, atol=1e-4, what=f"narrow conv deterministic={det}")
+            (out * go.permute(0, 2, 3, 1).reshape(-1, Cout).to(DEV)).sum().backward()
+            close(xd.grad, xr.grad.permute(0, 2, 3, 1).reshape(-1, Cin), rtol=1e-4, atol=1e-4, what="dgrad")
+            close(wd.grad, wr.grad, rtol=1e-4, atol=2e-4, what="wgrad"); close(bd.grad, br.grad, rtol=1e-4, atol=2e-4, what="bias grad")
+    finally:
+        K.set_deterministic(False)
         K.set_conv_math("f32")
+
+
+
