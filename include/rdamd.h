@@ -290,9 +290,16 @@ int rd_dense_to_rows(const float *dense, const int32_t *coords, int n, int C, in
  *    they can alias the fused 27-channel output of conv_offset_mask1; apply_sigmoid = 1 applies sigmoid to the mask.
  *    Forward  = rd_dcn_prep + rd_conv_fwd(index mode 3)            (bias is ALWAYS added, as in the reference)
  *    Backward = rd_conv_fwd (column gradient, weight kind 6) + rd_dcn_bwd_data + rd_conv_wgrad(index mode 3).
+ *    (The training path uses the column form below; index mode 3 -- sampling fused into the GEMM's operand staging -- stays available.)
  * ---------------------------------------------------------------------------------------------- */
 int rd_dcn_prep(const float *offset, int off_stride, const float *mask, int mask_stride, int apply_sigmoid, int B, int H, int W,
                 int Ho, int Wo, int KH, int KW, int stride, int pad, int dil, int32_t *samp_idx, float *samp_w, void *stream);
+/* Column form of the same convolution: col (out_rows, taps, C) = the bilinear-sampled, mask-modulated input rows of the sampling table
+ * of rd_dcn_prep.  Forward = rd_dcn_prep + rd_dcn_columns + rd_conv_fwd(col as (out_rows, taps*C) rows, 1 tap, linear index);
+ * weight gradient = rd_conv_wgrad over the same columns.  Replaces modulated_deformable_im2col_cuda
+ * (pcdet/ops/basicblock/src/cuda/modulated_deform_im2col_cuda.cuh:127-194) for all B samples in one launch. */
+int rd_dcn_columns(const float *x, int64_t in_rows, int C, const int32_t *samp_idx, const float *samp_w, int64_t out_rows, int taps,
+                   float *col, void *stream);
 /* x (B*H*W, C); colgrad (B*Ho*Wo, taps, C) = grad_out @ W per tap; outputs: grad_x (zeroed inside, atomics), grad of the
  * offset / mask rows (written with the given row strides; mask gradient is w.r.t. the pre-sigmoid value when apply_sigmoid). */
 int rd_dcn_bwd_data(const float *x, int C, const float *colgrad, const float *offset, int off_stride, const float *mask, int mask_stride,

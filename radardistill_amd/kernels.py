@@ -630,6 +630,18 @@ def dcn_prep(offset_base, off_stride, mask_base, mask_stride, apply_sigmoid, B, 
     return samp_idx, samp_w
 
 
+def dcn_columns(x_rows, samp_idx, samp_w):
+    """x_rows (in_rows, C), sampling table (out_rows, taps, 4) -> deformed, mask-modulated columns (out_rows, taps * C)."""
+    _chk(x_rows, f32, "dcn x", 2); _chk(samp_idx, i32, "dcn samp_idx", 3); _chk(samp_w, f32, "dcn samp_w", 3)
+    rows, taps = samp_idx.shape[0], samp_idx.shape[1]
+    C = x_rows.shape[1]
+    if samp_idx.shape != (rows, taps, 4) or samp_w.shape != (rows, taps, 4):
+        raise RuntimeError("dcn_columns: the sampling table must be (rows, taps, 4)")
+    col = torch.empty((rows, taps * C), dtype=f32, device=x_rows.device)
+    check(native.lib().rd_dcn_columns(_p(x_rows), x_rows.shape[0], C, _p(samp_idx), _p(samp_w), rows, taps, _p(col), _stream()), "rd_dcn_columns")
+    return col
+
+
 def conv_index_deform(samp_idx, samp_w):
     ix = ConvIndex()
     ix.mode = 3

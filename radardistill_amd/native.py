@@ -108,6 +108,7 @@ SIGNATURES = {
     "rd_rows_to_dense": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "rd_dense_to_rows": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "rd_dcn_prep": (c_int, [_P, c_int, _P, c_int, c_int] + [c_int] * 10 + [_P, _P, _P]),
+    "rd_dcn_columns": (c_int, [_P, c_i64, c_int, _P, _P, c_i64, c_int, _P, _P]),
     "rd_dcn_bwd_data": (c_int, [_P, c_int, _P, _P, c_int, _P, c_int, c_int] + [c_int] * 10 + [_P, _P, c_int, _P, c_int, _P]),
     "rd_afd_ws_bytes": (c_i64, [c_i64]),
     "rd_afd_fwd": (c_int, [_P, _P, _P, c_i64, c_int, c_int, _P, _P, _P, _P, c_i64, _P]),

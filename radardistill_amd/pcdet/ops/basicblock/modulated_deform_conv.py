@@ -12,8 +12,13 @@ import torch.nn as nn
 from torch.nn import init
 from torch.nn.modules.utils import _pair
 
+import os
+
 from radardistill_amd import autograd as A
 from radardistill_amd import kernels as K
+
+# DCNv2 as explicit deformed columns + plain GEMMs (default) or with the sampling fused into the GEMM's operand staging (RD_DCN_COLS=0)
+DCN_COLUMNS = os.environ.get("RD_DCN_COLS", "1") != "0"
 
 
 class _DCNFn(torch.autograd.Function):
@@ -31,18 +36,37 @@ class _DCNFn(torch.autograd.Function):
             raise RuntimeError("DCN: offset/mask/input shapes do not match the geometry")
         mask_base = om_rows[0:1, 2 * taps:]           # view: data_ptr of the first mask channel
         samp_idx, samp_w = K.dcn_prep(om_rows, S, mask_base, S, sig, B, H, W, Ho, Wo, k, stride, pad)
-        ix = K.conv_index_deform(samp_idx, samp_w)
-        wk = A.kernel_weight(weight, Cout, Cin, taps, 1)
-        out = K.conv_fwd(x_rows, wk, taps, bias.detach(), B * Ho * Wo, Cout, ix)
+        rows_o = B * Ho * Wo
+        col = None
+        if DCN_COLUMNS and x_rows.is_cuda and Cin % 4 == 0:
+            # column form: the sampled, modulated input rows are written once (rows x taps*Cin) and the convolution is a plain GEMM
+            # over them; the backward's weight gradient re-uses the same columns (kept: 75 MB at the CMA shapes)
+            col = K.dcn_columns(x_rows, samp_idx, samp_w)
+            lin = A.linear_spec(rows_o).fwd_ix
+            if A._b3_wsplit(taps * Cin, Cout):
+                out = K.conv_fwd(col, A.operand_weight_split(weight, Cout, Cin, taps, 1), 1, bias.detach(), rows_o, Cout, lin, w_split=True)
+            else:
+                out = K.conv_fwd(col, A.kernel_weight(weight, Cout, Cin, taps, 1), 1, bias.detach(), rows_o, Cout, lin)
+        else:         # sampling fused into the GEMM's operand staging (index mode 3)
+            ix = K.conv_index_deform(samp_idx, samp_w)
+            wk = A.kernel_weight(weight, Cout, Cin, taps, 1)
+            out = K.conv_fwd(x_rows, wk, taps, bias.detach(), rows_o, Cout, ix)
         ctx.geom, ctx.sig, ctx.out_hw = geom, sig, (Ho, Wo)
-        ctx.save_for_backward(x_rows, om_rows, weight, samp_idx, samp_w)
+        ctx.has_col = col is not None
+        if col is not None:
+            ctx.save_for_backward(x_rows, om_rows, weight, col)
+        else:
+            ctx.save_for_backward(x_rows, om_rows, weight, samp_idx, samp_w)
         ctx.bias_grad = bias.requires_grad
         ctx.bias_ref = bias
         return out
 
     @staticmethod
     def backward(ctx, go):
-        x_rows, om_rows, weight, samp_idx, samp_w = ctx.saved_tensors
+        if ctx.has_col:
+            x_rows, om_rows, weight, col = ctx.saved_tensors
+        else:
+            x_rows, om_rows, weight, samp_idx, samp_w = ctx.saved_tensors
         B, H, W, k, stride, pad = ctx.geom
         Ho, Wo = ctx.out_hw
         taps = k * k
@@ -57,10 +81,15 @@ class _DCNFn(torch.autograd.Function):
         g_om = torch.zeros_like(om_rows) if S > 3 * taps else torch.empty_like(om_rows)
         gx = K.dcn_bwd_data(x_rows, colgrad, om_rows, S, om_rows[0:1, 2 * taps:], S, ctx.sig, B, H, W, Ho, Wo, k, stride, pad,
                             g_om, S, g_om[0:1, 2 * taps:], S)
-        ix = K.conv_index_deform(samp_idx, samp_w)
         # parameter gradients: nobody reads them before the optimizer -> side stream (autograd.param_grad_stream)
-        gw = A.param_grad_stream(lambda: K.weight_layout(K.conv_wgrad(x_rows, go, taps, ix), Cout, Cin, taps, 4, False, out_shape=tuple(weight.shape)),
-                                 x_rows, go, samp_idx, samp_w, param=weight)
+        if ctx.has_col:
+            lin = A.linear_spec(rows_o).fwd_ix
+            gw = A.param_grad_stream(lambda: K.weight_layout(K.conv_wgrad(col, go, 1, lin), Cout, Cin, taps, 4, False, out_shape=tuple(weight.shape)),
+                                     col, go, param=weight)
+        else:
+            ix = K.conv_index_deform(samp_idx, samp_w)
+            gw = A.param_grad_stream(lambda: K.weight_layout(K.conv_wgrad(x_rows, go, taps, ix), Cout, Cin, taps, 4, False,
+                                                             out_shape=tuple(weight.shape)), x_rows, go, samp_idx, samp_w, param=weight)
         gb = A.param_grad_stream(lambda: K.colsum(go) if Cout % 4 == 0 else go.sum(0), go, param=ctx.bias_ref) if ctx.bias_grad else None
         return gx, g_om, gw, gb, None, None
 

@@ -840,7 +840,9 @@ def test_stride2_conv_data_gradient_subpixel_form_bf16x3(B, H, W, Cin, Cout, k, 
         close(xd.grad, xr.grad.permute(0, 2, 3, 1).reshape(-1, Cin), rtol=1e-4, atol=1e-4, what="dgrad (sub-pixel form)")
         close(wd.grad, wr.grad, rtol=1e-4, atol=2e-4, what="wgrad")
     finally:
-        K.set_conv_math("f32")@pytest.mark.gpu
+        K.set_conv_math("f32")
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride", [(2, 20, 24, 256, 27, 2), (1, 13, 11, 96, 27, 2), (2, 9, 16, 64, 5, 1), (1, 32, 32, 256, 32, 2)])
 def test_narrow_output_conv_split_k_bf16x3(B, H, W, Cin, Cout, stride):
     """conv_small.hip k_conv_narrow_b3 (the CMA blocks' 256 -> 27 DCNv2 offset / mask convolution: one wavefront per 32 output pixels,
@@ -873,6 +875,3 @@ def test_narrow_output_conv_split_k_bf16x3(B, H, W, Cin, Cout, stride):
     finally:
         K.set_deterministic(False)
         K.set_conv_math("f32")
-
-
-

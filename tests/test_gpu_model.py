@@ -30,9 +30,13 @@ def _bev_inputs(seed, B=1, S=16):
 
 
 # ------------------------------------------------------------------------------------------ DCNv2
+@pytest.mark.parametrize("columns", [True, False])
 @pytest.mark.parametrize("C,Cout,H,W,stride", [(64, 64, 9, 8, 2), (32, 96, 7, 7, 1), (256, 256, 16, 16, 2)])
-def test_dcn_forward_backward_vs_oracle(C, Cout, H, W, stride):
+def test_dcn_forward_backward_vs_oracle(C, Cout, H, W, stride, columns, monkeypatch):
+    """columns: the training path's form (rd_dcn_columns + plain GEMMs) / the sampling fused into the GEMM's operand staging (index mode 3)."""
+    from radardistill_amd.pcdet.ops.basicblock import modulated_deform_conv as MDC
     from radardistill_amd.pcdet.ops.basicblock.modulated_deform_conv import ModulatedDeformConv
+    monkeypatch.setattr(MDC, "DCN_COLUMNS", columns)
     rng = np.random.default_rng(C + H)
     B = 2
     Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
@@ -537,7 +541,7 @@ def test_bf16x3_conv_math_parity(golden_dir):
         TK.test_conv_transpose2d_forward_and_backward(4, 2, 1)
         TK.test_linear_as_one_tap_conv()
         TK.test_conv_epilogue_and_fused_stats()
-        test_dcn_forward_backward_vs_oracle(256, 256, 16, 16, 2)
+        test_dcn_forward_backward_vs_oracle(256, 256, 16, 16, 2, True, pytest.MonkeyPatch())
         TK.test_sparse_enc_c2_vs_oracle(False)
         test_dense_enc_golden(golden_dir)
         test_radar_distill_forward_golden(golden_dir)
