@@ -351,6 +351,7 @@ def main():
                  "exact fp32 on v_mfma_f32_32x32x2_f32")
         names = {
             "d3_128": ("k_conv_d3_b3<8,16,128> (dense stride-1 3x3 conv, forward and data gradient: halo-staged 8x16-pixel tile)", "k_conv_d3_b3<8, 16, 128"),
+            "d3_16x64": ("k_conv_d3_b3<8,16,64> (dense stride-1 3x3 conv, halo-staged 8x16-pixel x 64-channel tile: the 8192-row maps)", "k_conv_d3_b3<8, 16, 64"),
             "d3_64": ("k_conv_d3_b3<8,8,64> (dense stride-1 3x3 conv, halo-staged 8x8-pixel x 64-channel tile)", "k_conv_d3_b3<8, 8, 64"),
             128: ("k_conv_igemm%s<128,128> (gathered implicit-GEMM conv: sparse / 1x1 / strided / transposed, forward and data gradient)" % ("_b3" if b3 else ""),
                   "k_conv_igemm_b3<128, 128" if b3 else "k_conv_igemm<128, 128"),

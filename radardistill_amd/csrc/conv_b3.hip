@@ -1170,8 +1170,12 @@ bool launch_conv_d3_b3(const ConvArgs &a, hipStream_t st) {
         if (a.w_split) k_conv_d3_b3<8, 16, 128, true><<<grid, block, 0, st>>>(a, flip);
         else k_conv_d3_b3<8, 16, 128, false><<<grid, block, 0, st>>>(a, flip);
     } else {
-        static const int small = getenv("RD_D3_SMALL") ? atoi(getenv("RD_D3_SMALL")) : 0;     // tuning knob: 1 = 8x16x64, 2 = 8x8x128
+        // 8 x 16 pixels x 64 channels (wave tile 64 x 32: 6 LDS fragment reads per 6 MFMAs instead of 4 per 3) when that still gives every
+        // CU a workgroup -- the 8192-row 256 -> 256 layers, 30 launches per step: 20.09 -> 19.69 ms per step; smaller maps keep 8 x 8 x 64
+        // (twice the workgroups).  RD_D3_SMALL: 0 = always 8x8x64, 1 = 8x16x64 whenever the weights are pre-split, 2 = 8x8x128.
+        static const int small_env = getenv("RD_D3_SMALL") ? atoi(getenv("RD_D3_SMALL")) : -1;
         const int64_t rows64 = nb * cdiv(ix.Hout, 8) * cdiv(ix.Wout, 8);
+        const int small = small_env >= 0 ? small_env : (big_rows * cdiv(a.Cout, 64) >= 256 ? 1 : 0);
         if (small == 1 && a.w_split) {
             k_conv_d3_b3<8, 16, 64, true><<<dim3(xcd_grid(big_rows, cdiv(a.Cout, 64))), block, 0, st>>>(a, flip);
         } else if (small == 2 && a.w_split) {

@@ -286,13 +286,17 @@ def weight_layout_split_multi(jobs_dev, chunk_job_dev, chunk_group_dev, n_chunks
 
 def _kernel_tag(ix, in_rows, out_rows, Cin, Cout, taps, in_split, tile):
     """Which instantiation rd_conv_fwd launches (mirrors the dispatch in conv.hip / conv_b3.hip; used by bench.py's roofline only):
-    128 / 64 = gathered implicit-GEMM tile, "d3_128" / "d3_64" = halo-staged dense 3x3 kernel (bf16x3 mode)."""
+    128 / 64 = gathered implicit-GEMM tile, "d3_128" / "d3_16x64" / "d3_64" = halo-staged dense 3x3 kernel (bf16x3 mode; pre-split weights assumed for the middle one)."""
     if (get_conv_math() == "bf16x3" and ix.mode in (1, 2) and taps == 9 and ix.KH == 3 and ix.KW == 3 and ix.stride == 1 and ix.pad == 1
             and ix.Hin == ix.Hout and ix.Win == ix.Wout and Cin % 32 == 0 and not in_split and in_rows == out_rows
             and os.environ.get("RD_D3", "1") != "0"):
         nb = out_rows // (ix.Hout * ix.Wout)
-        big = nb * ((ix.Hout + 7) // 8) * ((ix.Wout + 15) // 16) * ((Cout + 127) // 128)
-        return "d3_128" if big >= 384 else "d3_64"
+        big_rows = nb * ((ix.Hout + 7) // 8) * ((ix.Wout + 15) // 16)
+        if big_rows * ((Cout + 127) // 128) >= 384:
+            return "d3_128"
+        small = os.environ.get("RD_D3_SMALL")
+        wide = small == "1" if small is not None else big_rows * ((Cout + 63) // 64) >= 256
+        return "d3_16x64" if wide else "d3_64"
     if (((tile == 64 and Cout >= 128) or Cout == 128) and ix.mode == 0 or (ix.mode == 2 and ix.stride == 2 and ix.Wout % 64 == 0 and Cout >= 128
                                                                       and os.environ.get("RD_TILE_TLINE", "1") != "0")) \
             and get_conv_math() == "bf16x3" and os.environ.get("RD_TILE_MID", "1") != "0":

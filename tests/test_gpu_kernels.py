@@ -656,6 +656,44 @@ def test_halo_wgrad_3x3_bf16x3(B, H, W, Cin, Cout):
     print("halo wgrad max err / max", float((got.cpu().double() - ref).abs().max()) / scale)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,kernel", [(2, 64, 64, 64, 256, "8x16x64"),      # 256 workgroups of the 8x16-pixel x 64-channel tile
+                                                   (3, 61, 70, 64, 160, "8x16x64"),      # ragged map, half-empty column tile
+                                                   (8, 64, 64, 32, 256, "8x16x128"),     # >= 384 big tiles
+                                                   (1, 20, 21, 64, 96, "8x8x64")])       # small map
+def test_halo_conv_3x3_tile_variants_bf16x3(B, H, W, Cin, Cout, kernel):
+    """k_conv_d3_b3 (dense stride-1 3x3, bf16x3 mode) in each of the tile shapes its launcher picks -- `kernel` names the one these
+    sizes select (launch_conv_d3_b3: 8x16x128 from 384 big tiles, 8x16x64 while that gives 256 workgroups, else 8x8x64) -- forward
+    with fused statistics, data gradient (mirrored taps) and weight gradient against torch in fp64."""
+    A, K, SP = _mods()
+    big_rows = B * ((H + 7) // 8) * ((W + 15) // 16)
+    picked = "8x16x128" if big_rows * ((Cout + 127) // 128) >= 384 else ("8x16x64" if big_rows * ((Cout + 63) // 64) >= 256 else "8x8x64")
+    assert picked == kernel
+    g = np.random.default_rng(H * 7 + Cout)
+    x = torch.from_numpy(g.normal(size=(B, Cin, H, W)).astype(np.float32))
+    w = torch.from_numpy((g.normal(size=(Cout, Cin, 3, 3)) / np.sqrt(9 * Cin)).astype(np.float32))
+    b = torch.from_numpy(g.normal(size=Cout).astype(np.float32))
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = F.conv2d(xr, wr, br, 1, 1)
+    go = torch.from_numpy(g.normal(size=tuple(ref.shape)).astype(np.float32))
+    (ref * go.double()).sum().backward()
+    ref_rows = ref.detach().permute(0, 2, 3, 1).reshape(-1, Cout)
+    K.set_conv_math("bf16x3")
+    try:
+        spec = A.dense_conv_spec(B, H, W, 3, 3, 1, 1)
+        xd = x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().to(DEV).requires_grad_(True)
+        wd, bd = torch.nn.Parameter(w.to(DEV)), torch.nn.Parameter(b.to(DEV))
+        stats = torch.zeros(2 * Cout, device=DEV)
+        A.begin_step(torch.device(DEV))
+        out = A.conv(xd, wd, bd, spec, Cout, stats)
+        close(out, ref_rows, rtol=1e-4, atol=1e-4, what="halo conv forward")
+        close(stats[:Cout], ref_rows.sum(0), rtol=1e-4, atol=1e-3); close(stats[Cout:], (ref_rows * ref_rows).sum(0), rtol=1e-4, atol=1e-3)
+        (out * go.permute(0, 2, 3, 1).reshape(-1, Cout).to(DEV)).sum().backward()
+        close(xd.grad, xr.grad.permute(0, 2, 3, 1).reshape(-1, Cin), rtol=1e-4, atol=1e-4, what="halo conv data gradient")
+        close(wd.grad, wr.grad, rtol=1e-4, atol=1e-3, what="weight gradient"); close(bd.grad, br.grad, rtol=1e-4, atol=1e-3, what="bias gradient")
+    finally:
+        K.set_conv_math("f32")
+
+
 @pytest.mark.parametrize("rows,C", [(8 * 32 * 32, 256), (37, 64), (5, 1024), (1, 256)])
 def test_layernorm_rows_vs_torch(rows, C):
     """layernorm.hip (one wavefront per channels-last row, shuffle reductions) against F.layer_norm on the CPU: output and the three
