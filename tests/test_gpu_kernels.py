@@ -415,8 +415,10 @@ def test_sparse_enc_c2_vs_oracle(training):
                 close(v, st["radar_backbone_3d." + k], what=k)
 
 
-@pytest.mark.parametrize("C,H,W,K", [(256, 16, 16, 7), (64, 9, 11, 7), (32, 5, 5, 3)])
+@pytest.mark.parametrize("C,H,W,K", [(256, 16, 16, 7), (64, 9, 11, 7), (32, 5, 5, 3), (96, 37, 33, 7), (36, 8, 8, 7)])
 def test_depthwise_conv_forward_and_backward(C, H, W, K):
+    """dwconv.hip: 7x7 with C % 32 == 0 takes the LDS-tiled kernels (16x16-pixel tiles: 37x33 has ragged tiles in both directions), other
+    shapes (3x3, C = 36) the plain ones."""
     A, K_, SP = _mods()
     rng = np.random.default_rng(C + H)
     B = 2
