@@ -209,8 +209,15 @@ bool launch_wgrad_d3_b3(const float *in, int in_rows, int Cin, const float *go, 
     int64_t chunks = 1;
     if (!g_deterministic) {
         double best = 1e30;
+        // ONE round on at most `res` CUs.  A workgroup of this kernel owns its CU's whole register file (8 waves x 256 VGPRs): with
+        // 256 of them resident nothing of the main stream -- the BatchNorm backward passes and data gradients this launch is meant
+        // to overlap with -- could start anywhere for the launch's duration (kernel trace: 91-99 us for a 33.6 MB BatchNorm pass
+        // that takes 30 us alone).  The weight-gradient stream has slack, the main stream is the critical path: measured step
+        // 19.41 ms at 256, 19.14 / 19.07 / 18.93 / 18.74 / 18.5 / 18.65 ms at 224 / 192 / 128 / 96 / 80 / 64, 19.9 ms at 48, 22.1 ms at 32.
+        static const int res = getenv("RD_WGRAD_D3_RES") ? std::max(1, atoi(getenv("RD_WGRAD_D3_RES"))) : 80;
         for (int64_t c = 1; c <= std::min<int64_t>(total_tiles, 256); ++c) {
-            const double cost = (double)cdiv(c * n_cc, 256) * (double)cdiv(total_tiles, c) * 1.9 + (double)c * n_cc * 0.23;
+            if (res < 256 && c * n_cc > res && c > 1) break;
+            const double cost = (double)cdiv(c * n_cc, res) * (double)cdiv(total_tiles, c) * 1.9 + (double)c * n_cc * 0.23;
             if (cost < best) { best = cost; chunks = c; }
         }
     }
