@@ -152,6 +152,12 @@ def cpu_baseline(grid, B=1):
     return out
 
 
+def cu_limited():
+    """Instantiation tags whose launches the library restricts to a share of the CUs (conv_wgrad_d3.hip, RD_WGRAD_D3_RES)."""
+    from radardistill_amd import autograd as A, kernels as K
+    return {"wgrad_d3"} if (A.WGRAD_STREAM[0] and K.WGRAD_D3_MAX_CUS < 256) else set()
+
+
 def main():
     args = parse()
     if args.other_math_steps < 0:
@@ -231,6 +237,8 @@ def main():
         by = {}
         for a_, b_, _, _, shp in rank_prof:
             by[shp[5]] = by.get(shp[5], 0.0) + a_.elapsed_time(b_)
+        for tag in cu_limited():          # kernels deliberately kept to a share of the chip do not compete for "dominant" (see below)
+            by.pop(tag, None)
         K.PROFILE_TAGS = {max(by, key=lambda k: by[k])} if by else None
     # an event pair costs the stream ~2 x 4 us of marker packets, so even the dominant kernel's ~25 launches are timed in every SECOND
     # step only (>= 3 steps), and the BatchNorm launches of the HBM figure in the first two instrumented steps
@@ -333,7 +341,12 @@ def main():
             by_kern[tag] = by_kern.get(tag, 0.0) + all_ms[i]
             fl_kern[tag] = fl_kern.get(tag, 0.0) + all_flops[i]
             n_kern[tag] = n_kern.get(tag, 0) + 1
-        dom = max(by_kern, key=lambda k: by_kern[k]) if by_kern else 128
+        # Kernels the library deliberately keeps to a share of the chip (the halo weight-gradient kernel runs on <= 80 CUs of its side
+        # stream so that the main stream can start work beside it: 19.4 -> 18.7 ms per step) have launch durations set by that share,
+        # not by their code; they are listed under `cu_limited_kernels` and the dominant kernel is chosen among the others.
+        limited = {t: by_kern[t] for t in cu_limited() if t in by_kern}
+        ranked = {k: v for k, v in by_kern.items() if k not in limited} or by_kern
+        dom = max(ranked, key=lambda k: ranked[k]) if ranked else 128
         sel = [p for p in timed if p[4][5] == dom]
         kernel_ms = [a.elapsed_time(b) for a, b, _, _, _ in sel]
         flops = [(f if pairs is None else float(pairs.item()) * f) for _, _, pairs, f, _ in sel]
@@ -414,6 +427,11 @@ def main():
                          "launches_per_step": n_launch // max(prof_steps, 1), "measured": roofline_note, "avg_launch_ms": round(avg_ms, 4),
                          "ms_per_step_by_kernel": {str(k): round(v / rank_steps, 3) for k, v in sorted(by_kern.items(), key=lambda kv: -kv[1])},
                          "algorithmic_tflops_by_kernel": {str(k): round(fl_kern[k] / (by_kern[k] * 1e-3) / 1e12, 1) for k in sorted(by_kern, key=lambda k: -by_kern[k])},
+                         "cu_limited_kernels": {t: {"max_cus": K.WGRAD_D3_MAX_CUS, "of": 256, "ms_per_step": round(v / rank_steps, 3),
+                                                    "algorithmic_tflops": round(fl_kern[t] / (v * 1e-3) / 1e12, 1),
+                                                    "note": "side stream, overlapped with the main stream; launched on a share of the chip by design, "
+                                                            "so its launch duration reflects that share (RD_WGRAD_D3_RES=256 gives it the whole chip: "
+                                                            "0.114 ms per launch alone, +0.7 ms per step)"} for t, v in limited.items()},
                          "time_share_of_step": round(sum(kernel_ms) / prof_steps / step_ms, 4),
                          "all_mfma_conv_share_of_step": round(sum(all_ms) / rank_steps / step_ms, 4)},
         }

@@ -247,6 +247,7 @@ def timing_event():
 # a list to which (start_event, end_event, algorithmic_flops) of every such launch is appended.  None = off (no overhead).
 CONV_PROFILE = None
 PROFILE_ALL = os.environ.get("RD_BENCH_SHAPES") == "all"          # diagnostic: also time the narrow (<= 64-channel) launches
+WGRAD_D3_MAX_CUS = int(os.environ.get("RD_WGRAD_D3_RES", "80"))          # mirrors launch_wgrad_d3_b3 (conv_wgrad_d3.hip): CUs its one round may occupy
 PROFILE_TAGS = None          # None: every profiled launch gets its pair of events; a set: only launches of these instantiation tags
 
 
