@@ -213,9 +213,8 @@ def main():
         return loss
 
     run_model.train()            # once, as train_one_epoch does (tools/train_utils/train_utils.py): the recursive mode switch costs ~1.5 ms
-    main_prio = int(os.environ.get("RD_MAIN_PRIO", "0"))
-    if main_prio:
-        torch.cuda.set_stream(torch.cuda.Stream(device, priority=main_prio))
+    from radardistill_amd.train import use_training_stream
+    use_training_stream(device, int(os.environ.get("RD_MAIN_PRIO", "-1")))          # the loop's stream: high priority (RD_MAIN_PRIO=0: torch's default stream)
     def barrier():
         D.barrier()
         torch.cuda.synchronize()

@@ -410,6 +410,19 @@ class AmpScaler:
         self._inv.copy_((1.0 / self._scale).reshape(1))
 
 
+def use_training_stream(device, priority=-1):
+    """Make a HIGH-priority HIP stream the current stream of `device` for the training loop (call once, before the first step) and
+    return it.  The step's critical path -- student forward, BatchNorm backward passes, data gradients -- then has its workgroups
+    dispatched ahead of the teacher's and the weight-gradient stream's whenever both wait for a CU: +1 % (18.6 -> 18.4 ms per step,
+    measured in alternation).  priority 0 keeps torch's default stream."""
+    if device.type != "cuda" or not priority:
+        return None
+    s = torch.cuda.Stream(device, priority=priority)
+    s.wait_stream(torch.cuda.current_stream(device))          # parameter uploads / initialisation enqueued so far
+    torch.cuda.set_stream(s)
+    return s
+
+
 def train_step(model, optimizer, lr_scheduler, model_func, batch, accumulated_iter, scaler=None):
     """One iteration of train_one_epoch (train_utils.py:44-64) without logging: returns (loss tensor, tb_dict).
     scaler: an AmpScaler for the reference's `--use_amp` loop (scale the loss, unscale + clip + step in one pass, update)."""
