@@ -37,6 +37,9 @@ int rd_set_deterministic(int on);
 int rd_get_deterministic(void);
 /* 1 if a gfx950 device is usable, 0 otherwise (never throws). */
 int rd_device_ok(void);
+/* Stream fork in one call: `to_stream` waits for everything enqueued on `from_stream` so far (hipEventRecord on a library-owned event of
+ * the waiting stream + hipStreamWaitEvent).  Host plumbing of the weight-gradient side stream (radardistill_amd/autograd.py). */
+int rd_stream_fork(void *from_stream, void *to_stream);
 
 /* ------------------------------------------------------------------------------------------------
  * A. Active-site index structures ("rulebooks").  Replaces spconv's hash-table indice-pair generation

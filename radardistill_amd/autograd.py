@@ -332,7 +332,7 @@ def _queue_wgrad_join(device, main):
     torch.autograd.Variable._execution_engine.queue_callback(_join)
 
 
-_PG_STATE = {}          # device -> (main stream of this backward pass, reusable event)
+_PG_STATE = {}          # device -> (main stream of this backward pass, its raw handle, the side stream's raw handle)
 # Tensors the side stream reads are HELD until the join instead of being marked with Tensor.record_stream: a recorded block costs the
 # caching allocator an event record when it is freed and an event query per later allocation (~200 tensors per step: 0.5 ms of HIP
 # runtime calls); with 288 GB of HBM the few GB of gradients that stay alive until the end of the backward pass are free.
@@ -419,7 +419,7 @@ def param_grad_stream(fn, *inputs, param=None):
     Must be called from inside an autograd Function's backward.
     Called ~150 times per step, so it avoids the Python-heavy torch.cuda helpers (current_stream / wait_stream / the stream context
     manager were ~40 us per call, 6 ms of host time per step): the main stream is looked up once per backward pass, the fork is one
-    re-recorded event, and the current stream is switched through the raw setter."""
+    C call (rd_stream_fork: event record + stream wait), and the current stream is switched through the raw setter."""
     dev = inputs[0].device
     side = _wgrad_stream(dev)
     if side is None or not _side_ok(param):
@@ -427,11 +427,10 @@ def param_grad_stream(fn, *inputs, param=None):
     st = _PG_STATE.get(dev)
     if st is None or not _WGRAD_JOIN_QUEUED[0]:
         main = torch.cuda.current_stream(dev)
-        st = _PG_STATE[dev] = (main, st[1] if st is not None else torch.cuda.Event())
+        st = _PG_STATE[dev] = (main, main.cuda_stream, side.cuda_stream)
         _queue_wgrad_join(dev, main)
-    main, ev = st
-    ev.record(main)
-    side.wait_event(ev)                       # the wait captures the event's state now; re-recording it later is fine
+    main, main_raw, side_raw = st
+    K.check(K.native.lib().rd_stream_fork(main_raw, side_raw), "rd_stream_fork")          # the side stream waits for the main stream's work so far
     _set_stream(side)
     try:
         out = fn()

@@ -21,6 +21,26 @@ extern "C" int rd_set_deterministic(int on) { rd::g_deterministic = on ? 1 : 0; 
 extern "C" int rd_get_deterministic(void) { return rd::g_deterministic; }
 extern "C" const char *rd_last_error(void) { return rd::g_err; }
 extern "C" int rd_abi_version(void) { return 2; }
+// Fork: `to` waits for everything enqueued on `from` so far.  One library-owned event per waiting stream, re-recorded on every call (a
+// wait captures the event's state when it is enqueued, so re-recording afterwards is safe).  Exists because the weight-gradient side
+// stream forks ~90 times per backward pass: one C call instead of torch's Event.record + Stream.wait_event (~3 us of Python each time).
+extern "C" int rd_stream_fork(void *from_stream, void *to_stream) {
+    static hipStream_t keys[16];
+    static hipEvent_t events[16];
+    static int n = 0;
+    hipStream_t to = reinterpret_cast<hipStream_t>(to_stream), from = reinterpret_cast<hipStream_t>(from_stream);
+    int i = 0;
+    while (i < n && keys[i] != to) ++i;
+    if (i == n) {
+        RD_REQUIRE(n < 16, "rd_stream_fork: more than 16 waiting streams");
+        RD_HIP(hipEventCreateWithFlags(&events[n], hipEventDisableTiming));
+        keys[n++] = to;
+    }
+    RD_HIP(hipEventRecord(events[i], from));
+    RD_HIP(hipStreamWaitEvent(to, events[i], 0));
+    return RD_OK;
+}
+
 extern "C" int rd_device_ok(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;

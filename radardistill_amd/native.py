@@ -56,6 +56,7 @@ SIGNATURES = {
     "rd_last_error": (ctypes.c_char_p, []),
     "rd_abi_version": (c_int, []),
     "rd_device_ok": (c_int, []),
+    "rd_stream_fork": (c_int, [_P, _P]),
     "rd_set_deterministic": (c_int, [c_int]),
     "rd_get_deterministic": (c_int, []),
     "rd_rankgrid_bytes": (c_i64, [c_i64]),

@@ -98,6 +98,11 @@ def main():
             for m in ("forward", "backward"):
                 if m in vars(cls):
                     setattr(cls, m, staticmethod(timed(f"F   {name}.{m}", vars(cls)[m].__func__)))
+    for name in ("param_grad_stream", "operand_weight_split", "defer_weight_layout", "kernel_weight", "split_activation", "zeros_accum", "zeros_stats",
+                 "_side_ok", "begin_step", "end_forward", "nchw_to_rows", "rows_to_nchw", "dense_conv_spec", "linear_spec", "bn_eval_scale_shift",
+                 "conv_inference", "conv_bn_act_train"):
+        if hasattr(A, name):
+            setattr(A, name, timed("A   " + name, getattr(A, name)))
     for name in ("empty", "empty_like", "zeros", "cat"):
         setattr(torch, name, timed("T   torch." + name, getattr(torch, name)))
     for name in ("record_stream", "contiguous", "permute", "reshape", "view"):
@@ -110,7 +115,7 @@ def main():
     host2 = time.perf_counter() - t0
     torch.cuda.synchronize()
     print(f"with wrappers: host loop {host2 / n * 1e3:.2f} ms/step; " + "  ".join(f"{k} {v / n * 1e3:.2f}" for k, v in phase.items()))
-    for prefix, title in (("C   ", "C-ABI calls (inside the library)"), ("K   ", "kernels.py wrappers (inclusive)"),
+    for prefix, title in (("C   ", "C-ABI calls (inside the library)"), ("K   ", "kernels.py wrappers (inclusive)"), ("A   ", "autograd.py helpers (inclusive)"),
                           ("F   ", "autograd Functions (inclusive)"), ("T   ", "torch allocation / cat")):
         rows = [(k, v) for k, v in ACC.items() if k.startswith(prefix)]
         tot = sum(v[1] for _, v in rows)
