@@ -427,6 +427,14 @@ int rd_nconv_fwd(const float *y, int ldy, const float *weight, const float *bias
                  const int32_t *cin_off, const int32_t *col_off, const int32_t *n_out, float *out, void *stream);
 int rd_nconv_dgrad(const float *grad_out, const float *weight, int B, int H, int W, int NO, int NB, const int32_t *cin_off,
                    const int32_t *col_off, const int32_t *n_out, float *grad_y, int ldy, void *stream);
+/* rd_nconv_dgrad FUSED with the backward of the train-mode BatchNorm + ReLU whose output y the narrow convolutions read (every
+ * column of the (rows, ldy) tensors must belong to a branch): x = BatchNorm input, (mean, rstd, scale, shift) of its forward
+ * (rd_bn_train_fwd), gamma may be NULL (= 1).  Writes grad_x (rows, ldy) and ACCUMULATES grad_gamma / grad_beta [ldy] (caller
+ * zero-fills); grad_y is never materialised (two launches that recompute it: 1.05 GB instead of 2.1 GB of traffic for the 352 MB
+ * tensor of 42 branches at B = 8).  Not available in deterministic mode (atomics). */
+int rd_nconv_dgrad_bn(const float *grad_out, const float *weight, const float *x, const float *gamma, const float *mean, const float *rstd,
+                      const float *scale, const float *shift, int B, int H, int W, int NO, int NB, const int32_t *cin_off,
+                      const int32_t *col_off, const int32_t *n_out, float *grad_x, int ldy, float *grad_gamma, float *grad_beta, void *stream);
 int rd_nconv_wgrad(const float *y, int ldy, const float *grad_out, int B, int H, int W, int NO, int NB, const int32_t *cin_off,
                    const int32_t *col_off, const int32_t *n_out, float *grad_w, void *stream);
 

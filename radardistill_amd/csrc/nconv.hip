@@ -38,6 +38,11 @@ struct NconvArgs {
     int cin_off[NC_MAXB];  // first channel of branch b in y
     int col_off[NC_MAXB];  // first output column of branch b
     int n_out[NC_MAXB];    // outputs of branch b (1..4)
+    // data gradient fused with the backward of the train-mode BatchNorm + ReLU in front of these convolutions (k_nconv_dgrad_bn)
+    const float *x = nullptr;                                  // BatchNorm input (rows, ldy): the first convolutions' raw output
+    const float *mean = nullptr, *rstd = nullptr, *scale = nullptr, *shift = nullptr, *gamma = nullptr;     // per channel, [ldy]
+    float *sum_g = nullptr, *sum_gx = nullptr;                 // pass 1 accumulates, pass 2 reads: [ldy] each
+    float inv_n = 0.f;
 };
 
 __device__ __forceinline__ float reduce16(float v) {
@@ -191,6 +196,101 @@ __global__ __launch_bounds__(256) void k_nconv_dgrad(const NconvArgs a) {
     else nconv_dgrad_body<NMAX>(a, lds);
 }
 
+// Data gradient FUSED with the BatchNorm + ReLU backward in front of the narrow convolutions.  The plain sequence is k_nconv_dgrad
+// (writes grad_y: 352 MB at B = 8, 42 branches) -> column reduction over (x, grad_y) -> apply pass over (x, grad_y) -> grad_x: 2.1 GB
+// of traffic for a gradient that costs <= 27 fma per element to recompute from the 42-channel grad_out.  Here grad_y never exists:
+//   PASS 1: recompute grad_y, mask it with the forward's ReLU decision (x * scale + shift > 0), accumulate sum(g) and
+//           sum(g * xhat) per channel (registers over the band, LDS over the 16 pixel groups, one atomic per channel and workgroup);
+//   PASS 2: recompute again and write grad_x = A g + B x + D straight away (the coefficients of k_bn_bwd_apply, norm.hip).
+// Both read x once: 0.35 + 0.7 GB.  Same work split as k_nconv_dgrad.
+template <int N, int PASS>
+__device__ __forceinline__ void nconv_dgrad_bn_body(const NconvArgs &a, float *lds, float *red) {
+    const int br = blockIdx.y, col0 = a.col_off[br], cin0 = a.cin_off[br];
+    const int bands = (a.H + NC_T - 1) / NC_T;
+    const int b = blockIdx.x / bands, y0 = (blockIdx.x % bands) * NC_T;
+    const int l16 = threadIdx.x & 15, pg = threadIdx.x >> 4;
+    const int c = cin0 + 4 * l16;
+    float w[N][9][4];
+    load_weights<N>(a, col0, l16, w);
+    const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.scale + c), sh = *reinterpret_cast<const f32x4 *>(a.shift + c);
+    const f32x4 mu = *reinterpret_cast<const f32x4 *>(a.mean + c), rs = *reinterpret_cast<const f32x4 *>(a.rstd + c);
+    f32x4 cA, cB, cD, s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    if (PASS == 2) {
+        const f32x4 sg = *reinterpret_cast<const f32x4 *>(a.sum_g + c), sgx = *reinterpret_cast<const f32x4 *>(a.sum_gx + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cA[j] = (a.gamma ? a.gamma[c + j] : 1.f) * rs[j];
+            cB[j] = -cA[j] * rs[j] * (sgx[j] * a.inv_n);
+            cD[j] = -cA[j] * (sg[j] * a.inv_n) - cB[j] * mu[j];
+        }
+    }
+    for (int x0 = 0; x0 < a.W; x0 += NC_T) {
+        for (int i = threadIdx.x; i < NC_HALO * NC_HALO * N; i += 256) {
+            const int hp = i / N, n = i % N;
+            const int gy = y0 - 1 + hp / NC_HALO, gx = x0 - 1 + hp % NC_HALO;
+            float v = 0.f;
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = a.go[((int64_t)(b * a.H + gy) * a.W + gx) * a.NO + col0 + n];
+            lds[hp * NC_MAXN + n] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = pg + 16 * i, py = p >> 3, px = p & 7;
+            const int gy = y0 + py, gx = x0 + px;
+            if (gy < a.H && gx < a.W) {
+                const int64_t off = ((int64_t)(b * a.H + gy) * a.W + gx) * a.ldy + c;
+                const f32x4 xv = *reinterpret_cast<const f32x4 *>(a.x + off);
+                f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float *gp = lds + ((py + 2 - t / 3) * NC_HALO + px + 2 - t % 3) * NC_MAXN;
+#pragma unroll
+                    for (int n = 0; n < N; ++n) {
+                        const float gv = gp[n];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) g[j] += gv * w[n][t][j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = fmaf(xv[j], sc[j], sh[j]) > 0.f ? g[j] : 0.f;
+                if (PASS == 1) {
+                    s1 += g;
+                    s2 += g * ((xv - mu) * rs);
+                } else {
+                    f32x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = fmaf(cA[j], g[j], fmaf(cB[j], xv[j], cD[j]));
+                    *reinterpret_cast<f32x4 *>(a.out + off) = o;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (PASS == 1) {
+        // 16 pixel groups -> one value per channel: red[pg][2][64]
+        *reinterpret_cast<f32x4 *>(red + (pg * 2 + 0) * NC_CB + 4 * l16) = s1;
+        *reinterpret_cast<f32x4 *>(red + (pg * 2 + 1) * NC_CB + 4 * l16) = s2;
+        __syncthreads();
+        if (threadIdx.x < 2 * NC_CB) {
+            const int which = threadIdx.x / NC_CB, cc = threadIdx.x % NC_CB;
+            float v = 0.f;
+            for (int q = 0; q < 16; ++q) v += red[(q * 2 + which) * NC_CB + cc];
+            atomicAdd((which ? a.sum_gx : a.sum_g) + cin0 + cc, v);
+        }
+    }
+}
+
+template <int NMAX, int PASS>
+__global__ __launch_bounds__(256) void k_nconv_dgrad_bn(const NconvArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[NC_HALO * NC_HALO * NC_MAXN];
+    __shared__ __attribute__((aligned(16))) float red[16 * 2 * NC_CB];
+    const int n = a.n_out[blockIdx.y];
+    if (n == 1) nconv_dgrad_bn_body<1, PASS>(a, lds, red);
+    else if (n == 2) nconv_dgrad_bn_body<2, PASS>(a, lds, red);
+    else if (n == 3 || NMAX == 3) nconv_dgrad_bn_body<3, PASS>(a, lds, red);
+    else nconv_dgrad_bn_body<NMAX, PASS>(a, lds, red);
+}
+
 // grad_w[col0 + n][c][t] += sum_p go[p][col0 + n] * y[p + d_t][cin0 + c]   (fp32 atomics combine the bands)
 // ORDERED (rd_set_deterministic(1)): grid.x == 1, the workgroup walks every (sample, band) itself and the 16 pixel groups are
 // combined in group order -- one contributor per output element, no atomics.
@@ -331,6 +431,30 @@ extern "C" int rd_nconv_dgrad(const float *grad_out, const float *weight, int B,
     if (max_width(a) <= 3) k_nconv_dgrad<3><<<grid, 256, 0, S(stream)>>>(a);
     else k_nconv_dgrad<4><<<grid, 256, 0, S(stream)>>>(a);
     return check_launch("rd_nconv_dgrad");
+}
+
+extern "C" int rd_nconv_dgrad_bn(const float *grad_out, const float *weight, const float *x, const float *gamma, const float *mean,
+                                 const float *rstd, const float *scale, const float *shift, int B, int H, int W, int NO, int NB,
+                                 const int32_t *cin_off, const int32_t *col_off, const int32_t *n_out, float *grad_x, int ldy,
+                                 float *grad_gamma, float *grad_beta, void *stream) {
+    NconvArgs a{};
+    int rc = fill_args(a, "rd_nconv_dgrad_bn", B, H, W, ldy, NO, NB, cin_off, col_off, n_out);
+    if (rc) return rc;
+    RD_REQUIRE(grad_out && weight && x && mean && rstd && scale && shift && grad_x && grad_gamma && grad_beta, "rd_nconv_dgrad_bn: null pointer");
+    RD_REQUIRE(!g_deterministic, "rd_nconv_dgrad_bn: the fused form combines its partial sums with atomics; use rd_nconv_dgrad + rd_bn_bwd");
+    a.go = grad_out; a.w = weight; a.out = grad_x; a.x = x; a.gamma = gamma; a.mean = mean; a.rstd = rstd; a.scale = scale; a.shift = shift;
+    a.sum_g = grad_beta; a.sum_gx = grad_gamma;          // = the BatchNorm's parameter gradients (zero-filled by the caller)
+    a.inv_n = 1.0f / (float)((int64_t)B * H * W);
+    dim3 grid((unsigned)(B * cdiv(H, NC_T)), (unsigned)NB);
+    hipStream_t st = S(stream);
+    if (max_width(a) <= 3) {
+        k_nconv_dgrad_bn<3, 1><<<grid, 256, 0, st>>>(a);
+        k_nconv_dgrad_bn<3, 2><<<grid, 256, 0, st>>>(a);
+    } else {
+        k_nconv_dgrad_bn<4, 1><<<grid, 256, 0, st>>>(a);
+        k_nconv_dgrad_bn<4, 2><<<grid, 256, 0, st>>>(a);
+    }
+    return check_launch("rd_nconv_dgrad_bn");
 }
 
 extern "C" int rd_nconv_wgrad(const float *y, int ldy, const float *grad_out, int B, int H, int W, int NO, int NB, const int32_t *cin_off,

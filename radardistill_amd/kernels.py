@@ -844,6 +844,25 @@ def nconv_dgrad(grad_out, weight, B, H, W, tab, ldy):
     return gy
 
 
+def nconv_dgrad_bn(grad_out, weight, x, gamma, side, B, H, W, tab):
+    """Data gradient of the narrow convolutions fused with the backward of the train-mode BatchNorm + ReLU in front of them.
+    x (rows, NB*64): the BatchNorm's input; side: its (4, C) [mean | rstd | scale | shift] -> grad_x, grad_gamma, grad_beta."""
+    _chk(grad_out, f32, "nconv grad_out", 2); _chk(x, f32, "bn input", 2)
+    rows, C = x.shape
+    if grad_out.shape != (B * H * W, tab.no) or tuple(weight.shape) != (tab.no, 64, 3, 3) or rows != B * H * W or C != tab.nb * 64:
+        raise RuntimeError("nconv_dgrad_bn: shape mismatch (every channel of x must belong to a branch)")
+    if _chk(side, f32, "bn side", 2).shape != (4, C) or (gamma is not None and _chk(gamma, f32, "gamma").numel() != C):
+        raise RuntimeError("nconv_dgrad_bn: side must be (4, C), gamma (C,)")
+    from . import autograd as _A
+    g2 = _A.zeros_accum(2 * C, x.device)            # [grad_gamma | grad_beta]
+    gx = torch.empty_like(x)
+    sp = side.data_ptr()
+    check(native.lib().rd_nconv_dgrad_bn(_p(grad_out), _p(_chk(weight, f32, "nconv weight")), _p(x), _p(gamma), sp, sp + 4 * C, sp + 8 * C, sp + 12 * C,
+                                         B, H, W, tab.no, tab.nb, tab.cin, tab.col, tab.n, _p(gx), C, _p(g2), g2.data_ptr() + 4 * C, _stream()),
+          "rd_nconv_dgrad_bn")
+    return gx, g2[:C], g2[C:]
+
+
 def nconv_wgrad(y, grad_out, B, H, W, tab):
     _nconv_chk(y, B, H, W, tab, "nconv input")
     _chk(grad_out, f32, "nconv grad_out", 2)

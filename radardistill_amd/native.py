@@ -151,6 +151,7 @@ SIGNATURES = {
     "rd_layernorm_bwd": (c_int, [_P, _P, c_i64, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "rd_nconv_fwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "rd_nconv_dgrad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
+    "rd_nconv_dgrad_bn": (c_int, [_P] * 8 + [c_int] * 5 + [_P, _P, _P, _P, c_int, _P, _P, _P]),
     "rd_nconv_wgrad": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
 }
 

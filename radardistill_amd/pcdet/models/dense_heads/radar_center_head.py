@@ -183,11 +183,13 @@ class _BranchBatch:
             with torch.no_grad():
                 rm = torch.cat([bn.running_mean for bn in bns])
                 rv = torch.cat([bn.running_var for bn in bns])
-            y = A.bn_act_train_tensors(raw, gamma, beta, rm, rv, float(bns[0].eps), float(bns[0].momentum), act=1, stats=stats, modules=bns)
+            # BatchNorm + ReLU + the 42 narrow convolutions as one autograd node (the gradient of the 352 MB activation tensor is
+            # never written: autograd.bn_relu_nconv_train)
+            out = A.bn_relu_nconv_train(raw, gamma, beta, rm, rv, float(bns[0].eps), float(bns[0].momentum), stats, bns,
+                                        cat('w2', 4, 'weight'), cat('b2', 4, 'bias'), B, H, W, self.tab)
             with torch.no_grad():
                 torch._foreach_copy_([bn.running_mean for bn in bns], list(rm.split(64)))
                 torch._foreach_copy_([bn.running_var for bn in bns], list(rv.split(64)))
-            out = A.nconv(y, cat('w2', 4, 'weight'), cat('b2', 4, 'bias'), B, H, W, self.tab)
         else:
             return None                       # eval-mode BatchNorm with gradients: rare, the per-branch path handles it
         o4 = out.view(B, H, W, self.no)
