@@ -441,6 +441,50 @@ def test_depthwise_conv_forward_and_backward(C, H, W, K):
 
 
 @pytest.mark.parametrize("B,H,W,n_list", [(2, 16, 16, (1, 2, 3, 2, 2, 1, 1)), (1, 13, 10, (3, 4, 1)), (3, 8, 24, (2,))])
+def test_batchnorm_relu_narrow_convs_fused_node_vs_torch(B, H, W, n_list):
+    """autograd.bn_relu_nconv_train (train-mode BatchNorm + ReLU + the branches' narrow convolutions as one node; backward =
+    rd_nconv_dgrad_bn, which recomputes the activation gradient inside the BatchNorm backward's two passes) against torch in fp64:
+    output, running statistics, gradients of the BatchNorm input, gamma, beta, conv weights and bias -- and against the unfused two-node
+    path of the same library (deterministic mode takes it)."""
+    A, K, SP = _mods()
+    rng = np.random.default_rng(B * 10 + W)
+    NB = len(n_list)
+    C = NB * 64
+    cols = np.concatenate([[0], np.cumsum(n_list)]).tolist()
+    NO = cols[-1]
+    raw = torch.from_numpy(rng.normal(0.3, 1.0, size=(B, H, W, C)).astype(np.float32))
+    gamma = torch.from_numpy(rng.uniform(0.5, 1.5, size=C).astype(np.float32)); beta = torch.from_numpy(rng.normal(0, 0.3, size=C).astype(np.float32))
+    w = torch.from_numpy((rng.normal(size=(NO, 64, 3, 3)) * 0.1).astype(np.float32)); b = torch.from_numpy(rng.normal(size=NO).astype(np.float32))
+    go = torch.from_numpy(rng.normal(size=(B, H, W, NO)).astype(np.float32))
+    rr, gr, br_, wr, cr = [t.double().requires_grad_(True) for t in (raw, gamma, beta, w, b)]
+    yr = F.relu(F.batch_norm(rr.permute(0, 3, 1, 2), None, None, gr, br_, True, 0.0, 1e-3))
+    ref = torch.cat([F.conv2d(yr[:, 64 * i:64 * i + 64], wr[cols[i]:cols[i + 1]], cr[cols[i]:cols[i + 1]], padding=1) for i in range(NB)], dim=1)
+    (ref.permute(0, 2, 3, 1) * go.double()).sum().backward()
+    tab = K.BranchTable([64 * i for i in range(NB)], cols[:-1], list(n_list))
+    res = []
+    for det in (False, True):
+        K.set_deterministic(det)
+        try:
+            rd = raw.reshape(-1, C).to(DEV).requires_grad_(True)
+            gd, bd, wd, cd = [t.to(DEV).requires_grad_(True) for t in (gamma, beta, w, b)]
+            rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+            A.begin_step(torch.device(DEV))
+            out = A.bn_relu_nconv_train(rd, gd, bd, rm, rv, 1e-3, 0.01, None, (), wd, cd, B, H, W, tab)
+            (out * go.reshape(-1, NO).to(DEV)).sum().backward()
+            A.end_forward()
+        finally:
+            K.set_deterministic(False)
+        close(out, ref.detach().permute(0, 2, 3, 1).reshape(-1, NO), rtol=1e-4, atol=1e-4, what=f"output det={det}")
+        close(rd.grad, rr.grad.reshape(-1, C), rtol=1e-3, atol=2e-5, what=f"grad input det={det}")
+        close(gd.grad, gr.grad, rtol=1e-3, atol=2e-4, what="grad gamma"); close(bd.grad, br_.grad, rtol=1e-3, atol=2e-4, what="grad beta")
+        close(wd.grad, wr.grad, rtol=1e-3, atol=2e-4, what="grad w"); close(cd.grad, cr.grad, rtol=1e-3, atol=2e-4, what="grad bias")
+        x2 = raw.reshape(-1, C).double()
+        close(rm, 0.01 * x2.mean(0), rtol=1e-4, atol=1e-6, what="running mean"); close(rv, 0.99 + 0.01 * x2.var(0, unbiased=True), rtol=1e-4, atol=1e-6)
+        res.append(rd.grad.clone())
+    close(res[0], res[1], rtol=1e-4, atol=1e-5, what="fused vs two-node input gradient")
+
+
+@pytest.mark.parametrize("B,H,W,n_list", [(2, 16, 16, (1, 2, 3, 2, 2, 1, 1)), (1, 13, 10, (3, 4, 1)), (3, 8, 24, (2,))])
 def test_narrow_branch_convs_forward_and_backward(B, H, W, n_list):
     """rd_nconv_{fwd,dgrad,wgrad} (all head branches' final 64 -> n convs in one launch) vs torch conv2d per branch."""
     A, K, SP = _mods()
