@@ -123,7 +123,9 @@ class FusedAdamOneCycle:
             mb = float(bucket_mb if bucket_mb is not None else os.environ.get("RD_DDP_BUCKET_MB", "25"))
             self.buckets = GradBuckets([p.numel() for p in self.params], int(mb * (1 << 20)))
             self._works = []
-            self._comm_stream = torch.cuda.Stream(self.params[0].device) if self.params[0].is_cuda else None
+            # high priority, like the training loop's own stream (use_training_stream): the collectives' few, long-lived workgroups
+            # must not queue behind the compute streams' dispatches
+            self._comm_stream = torch.cuda.Stream(self.params[0].device, priority=-1) if self.params[0].is_cuda else None
             A.DEFER_LAYOUT[0] = False          # a bucket is packed mid-backward: every gradient must be complete when its hook fires
             for i, p in enumerate(self.params):
                 p.register_post_accumulate_grad_hook(lambda _p, i=i: self._grad_ready(i))
