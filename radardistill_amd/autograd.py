@@ -456,9 +456,15 @@ def _defer_layout_ok(param):
     return DEFER_LAYOUT[0] and WGRAD_STREAM[0] and param.is_cuda and _side_ok(param)
 
 
-def _flush_deferred_layouts():
+def _flush_deferred_layouts(only_accumulated=False):
+    """only_accumulated: mid-backward flush (a gradient bucket is about to be packed): only the jobs whose parameter already HAS its
+    gradient -- for the others AccumulateGrad has not run yet and may still decide to clone the destination."""
     from .native import LayoutJob
-    jobs, _DEFERRED_LAYOUT[:] = list(_DEFERRED_LAYOUT), []
+    if only_accumulated:
+        jobs = [j for j in _DEFERRED_LAYOUT if j[2].grad is not None]
+        _DEFERRED_LAYOUT[:] = [j for j in _DEFERRED_LAYOUT if j[2].grad is None]
+    else:
+        jobs, _DEFERRED_LAYOUT[:] = list(_DEFERRED_LAYOUT), []
     for i in range(0, len(jobs), 96):
         part = jobs[i:i + 96]
         arr = (LayoutJob * len(part))()

@@ -126,7 +126,7 @@ class FusedAdamOneCycle:
             # high priority, like the training loop's own stream (use_training_stream): the collectives' few, long-lived workgroups
             # must not queue behind the compute streams' dispatches
             self._comm_stream = torch.cuda.Stream(self.params[0].device, priority=-1) if self.params[0].is_cuda else None
-            A.DEFER_LAYOUT[0] = False          # a bucket is packed mid-backward: every gradient must be complete when its hook fires
+            # (a bucket is packed mid-backward: _launch_bucket first runs the deferred weight-gradient re-layouts that are due)
             for i, p in enumerate(self.params):
                 p.register_post_accumulate_grad_hook(lambda _p, i=i: self._grad_ready(i))
             # gradients delivered outside autograd's AccumulateGrad (autograd.ConcatLeaves) announce themselves here
@@ -161,6 +161,12 @@ class FusedAdamOneCycle:
         comm.wait_event(ev)
         side = A._WGRAD_STREAMS.get(dev)
         if side is not None:
+            if A._DEFERRED_LAYOUT:                 # the re-layouts of this bucket's (and every other accumulated) gradients: one launch
+                A._set_stream(side)
+                try:
+                    A._flush_deferred_layouts(only_accumulated=True)
+                finally:
+                    A._set_stream(main)
             comm.wait_stream(side)                 # weight gradients are produced on the side stream
         base = self.flat_grad.data_ptr()
         with torch.cuda.stream(comm):
