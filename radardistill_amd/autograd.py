@@ -361,18 +361,19 @@ def _side_ok(param):
 
 
 # A parameter gradient that reaches its leaves without autograd's AccumulateGrad nodes (ConcatLeaves below) still has to reach whoever
-# listens for "this parameter's gradient is complete" (FlatAdam's bucketed all-reduce): listeners are called with the leaf.
+# listens for "this parameter's gradient is complete" (FlatAdam's bucketed all-reduce): listeners are called with the list of leaves.
 GRAD_LISTENERS = []
 
 
-def deliver_grad(leaf, g):
-    """leaf.grad = g (or += g when the leaf already holds a gradient), then tell the listeners."""
-    if leaf.grad is None:
-        leaf.grad = g
-    else:
-        leaf.grad = leaf.grad + g
+def deliver_grads(leaves, grads):
+    """leaf.grad = g (or += g when the leaf already holds a gradient) for every pair, then tell the listeners once with the list."""
+    for leaf, g in zip(leaves, grads):
+        if leaf.grad is None:
+            leaf.grad = g
+        else:
+            leaf.grad = leaf.grad + g
     for cb in GRAD_LISTENERS:
-        cb(leaf)
+        cb(leaves)
 
 
 class ConcatLeaves:
@@ -408,8 +409,7 @@ class ConcatLeaves:
 
     def _distribute(self, cat):
         # cat.grad itself stays until the next refresh(): a deferred weight re-layout finds its destination through it
-        for leaf, v in zip(self.leaves, cat.grad.split(self.sizes)):
-            deliver_grad(leaf, v)
+        deliver_grads(self.leaves, cat.grad.split(self.sizes))
 
 
 def param_grad_stream(fn, *inputs, param=None):

@@ -133,10 +133,16 @@ class FusedAdamOneCycle:
             index = {id(p): i for i, p in enumerate(self.params)}
             me = weakref.ref(self)
 
-            def _delivered(leaf):
-                opt, i = me(), index.get(id(leaf))
-                if opt is not None and i is not None and opt.params[i] is leaf:
-                    opt._grad_ready(i)
+            def _delivered(leaves):
+                opt = me()
+                if opt is None:
+                    return
+                for leaf in leaves:
+                    i = index.get(id(leaf))
+                    if i is not None and opt.params[i] is leaf:
+                        b = opt.buckets.ready(i)
+                        if b is not None:
+                            opt._launch_bucket(b)
 
             A.GRAD_LISTENERS[:] = [cb for cb in A.GRAD_LISTENERS if getattr(cb, '_owner', lambda: None)() is not None]
             _delivered._owner = me
