@@ -10,6 +10,10 @@ sweeps: 512 x 512 BEV (0.2 m pillars), 35k LiDAR + 2k radar points and 30 boxes 
 A "step" = one such training iteration on one batch; inputs are resident in HBM before the timed region.  One process per
 GPU; N > 1 shards samples over ranks (weak scaling) with DDP gradient all-reduce over RCCL.
 Prints ONE JSON line on rank 0 (metric: samples/sec, whole job).
+
+`--gpus N` with N > 1 and no torchrun environment starts the N rank processes itself (child processes, one per GPU, before this
+process touches the GPU -- the role of tools/scripts/dist_train.sh:10 / torch_train.sh:17 of the reference) and relays rank 0's
+JSON line; under torchrun WORLD_SIZE must equal --gpus (anything else is an error, never a silent 1-GPU run).
 """
 import argparse
 import json
@@ -47,6 +51,44 @@ def parse():
     ap.add_argument("--cpu-baseline-grid", type=int, default=512)
     ap.add_argument("--cpu-baseline-batch", type=int, default=1)
     return ap.parse_args()
+
+
+def spawn_ranks(n, argv):
+    """Start `n` rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, as torchrun sets them),
+    wait for all of them and return the worst exit code.  The parent never initialises the GPU; rank 0 inherits stdout and prints
+    the JSON line, every rank inherits stderr.  A rank that dies takes the others down (they would wait in a collective forever)."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc, alive = 0, list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:          # the exact children started above, by handle
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def check_world(args_gpus, world):
+    """--gpus is a contract with the caller: the run must use exactly that many ranks."""
+    if args_gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args_gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args_gpus} "
+                         f"(or without torchrun: bench.py starts the ranks itself)")
 
 
 def build(cfg_path, grid, device):
@@ -152,6 +194,106 @@ def cpu_baseline(grid, B=1):
     return out
 
 
+def kernel_names(b3):
+    """instantiation tag (kernels._kernel_tag / conv_wgrad) -> (description, rocprofv3 kernel-name prefix)."""
+    names = {
+        "d3_128": ("k_conv_d3_b3<8,16,128> (dense stride-1 3x3 conv, forward and data gradient: halo-staged 8x16-pixel tile)", "k_conv_d3_b3<8, 16, 128"),
+        "d3_16x64": ("k_conv_d3_b3<8,16,64> (dense stride-1 3x3 conv, halo-staged 8x16-pixel x 64-channel tile: the 8192-row maps)", "k_conv_d3_b3<8, 16, 64"),
+        "d3_64": ("k_conv_d3_b3<8,8,64> (dense stride-1 3x3 conv, halo-staged 8x8-pixel x 64-channel tile)", "k_conv_d3_b3<8, 8, 64"),
+        128: ("k_conv_igemm%s<128,128> (gathered implicit-GEMM conv: sparse / 1x1 / strided / transposed, forward and data gradient)" % ("_b3" if b3 else ""),
+              "k_conv_igemm_b3<128, 128" if b3 else "k_conv_igemm<128, 128"),
+        64: ("k_conv_igemm%s<64,64> (gathered implicit-GEMM conv, 64x64 tiles)" % ("_b3" if b3 else ""), "k_conv_igemm_b3<64, 64" if b3 else "k_conv_igemm<64, 64"),
+        "64x128_table": ("k_conv_igemm_b3<64,128,..,table> (gathered implicit-GEMM conv of the sparse layers, neighbour-table geometry, 64-row x "
+                         "128-channel tiles)", "k_conv_igemm_b3<64, 128, false, false, 2"),
+        "64x128_dense": ("k_conv_igemm_b3<64,128,..,dense> (stride-2 transposed convs, one output line per tile)", "k_conv_igemm_b3<64, 128, false, false, 3"),
+        "64_table": ("k_conv_igemm_b3<64,64,..,table> (gathered implicit-GEMM conv, sparse layers, 64x64 tiles)", "k_conv_igemm_b3<64, 64, false, false, 2"),
+        "64_dense": ("k_conv_igemm_b3<64,64,..,dense> (1x1 projections, strided convs: dense geometry, 64x64 tiles)", "k_conv_igemm_b3<64, 64, false, false, 3"),
+        "128_table": ("k_conv_igemm_b3<128,128,..,table> (gathered implicit-GEMM conv, large sparse layers)", "k_conv_igemm_b3<128, 128, false, false, 2"),
+        "128_dense": ("k_conv_igemm_b3<128,128,..,dense> (large dense-geometry layers)", "k_conv_igemm_b3<128, 128, false, false, 3"),
+        "128x64_table": ("k_conv_igemm_b3<128,64,..,table> (large sparse layers with <= 64 output channels)", "k_conv_igemm_b3<128, 64, false, false, 2"),
+        "128x64_dense": ("k_conv_igemm_b3<128,64,..,dense>", "k_conv_igemm_b3<128, 64, false, false, 3"),
+        "wgrad_d3": ("k_conv_wgrad_d3_b3 (weight gradient of dense stride-1 3x3 convs: 8x8-pixel grad_out tile + 10x10 input halo staged once, "
+                     "all 9 taps per staged tile, ds_read_b64_tr_b16 fragments, 8 waves x (32 co x 32 ci x 9 taps))", "k_conv_wgrad_d3_b3"),
+        "wgrad_b3_128": ("k_conv_wgrad_tr_b3<128> (gathered weight gradient GEMM: M = Cout tile 128, N = Cin tile 128 of one tap, K = rows; "
+                         "row-major LDS images read with ds_read_b64_tr_b16; row chunks combined with fp32 atomics)", "k_conv_wgrad_tr_b3<128"),
+        "wgrad_b3_64": ("k_conv_wgrad_tr_b3<64> (gathered weight gradient GEMM, Cin tile 64)", "k_conv_wgrad_tr_b3<64"),
+        "wgrad_b3_deform_128": ("k_conv_wgrad_b3<true,128> (DCNv2 weight gradient: input rows blended from 4 bilinear corners while staged)", "k_conv_wgrad_b3<true, 128"),
+        "wgrad_f32_128": ("k_conv_wgrad<false,128> (weight gradient GEMM, exact fp32 MFMA)", "k_conv_wgrad<false, 128"),
+        "wgrad_f32_64": ("k_conv_wgrad<false,64> (weight gradient GEMM, exact fp32 MFMA, Cin tile 64)", "k_conv_wgrad<false, 64"),
+        "wgrad_f32_deform_128": ("k_conv_wgrad<true,128> (DCNv2 weight gradient, exact fp32 MFMA)", "k_conv_wgrad<true, 128"),
+        "wgrad_f32_deform_64": ("k_conv_wgrad<true,64> (DCNv2 weight gradient, exact fp32 MFMA)", "k_conv_wgrad<true, 64"),
+    }
+    return names
+
+
+def _flops_of(p):
+    _, _, pairs, f, _ = p
+    return f if pairs is None else float(pairs.item()) * f
+
+
+def mfma_roofline(timed, table, table_steps, prof_steps, math, limited_tags=()):
+    """Roofline entry of the dominant MFMA convolution instantiation.  `table`: events of EVERY MFMA launch of `table_steps` steps
+    (ranks the instantiations by summed time); `timed`: events of the launches inside the timed region (`prof_steps` instrumented
+    steps).  achieved = ALGORITHMIC flops (dense 2 k^2 Cin Cout rows, sparse 2 pairs Cin Cout) / HIP-event duration."""
+    b3 = math == "bf16x3"
+    all_ms = [a.elapsed_time(b) for a, b, _, _, _ in table]
+    all_flops = [_flops_of(p) for p in table]
+    by_kern, fl_kern = {}, {}
+    for i, p in enumerate(table):
+        tag = p[4][5]
+        by_kern[tag] = by_kern.get(tag, 0.0) + all_ms[i]
+        fl_kern[tag] = fl_kern.get(tag, 0.0) + all_flops[i]
+    limited = {t: by_kern[t] for t in limited_tags if t in by_kern}
+    ranked = {k: v for k, v in by_kern.items() if k not in limited} or by_kern
+    dom = max(ranked, key=lambda k: ranked[k]) if ranked else 128
+    sel = [p for p in timed if p[4][5] == dom]
+    kernel_ms = [a.elapsed_time(b) for a, b, _, _, _ in sel]
+    flops = [_flops_of(p) for p in sel]
+    n = len(sel)
+    avg_ms = sum(kernel_ms) / max(n, 1)
+    achieved = (sum(flops) / max(n, 1)) / (avg_ms * 1e-3) / 1e12 if n else 0.0
+    kname, pmc_key = kernel_names(b3).get(dom, (str(dom), str(dom)))
+    peak = PEAK_BF16_MFMA_TFLOPS if b3 else PEAK_F32_MFMA_TFLOPS
+    arith = ("fp32 operands split to bf16 hi+lo, 3 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate" if b3 else
+             "exact fp32 on v_mfma_f32_32x32x2_f32")
+    entry = {"bound": "mfma", "kernel": kname + "; " + arith, "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+             "frac": round(achieved / peak, 4),
+             "flops": "algorithmic (SURVEY 8(d)): dense 2*k*k*Cin*Cout*rows, sparse 2*pairs*Cin*Cout",
+             "algorithmic_flops_per_launch": round(sum(flops) / max(n, 1)),
+             # what `traffic` (PMC, all launches of this kernel in the profiled command) compares with: input + output +
+             # weights touched once, averaged over the same launches (shape tuple = rows_in, Cin, Cout, taps)
+             "algorithmic_bytes_per_launch": round(sum(4.0 * (p[4][0] * p[4][1] + p[4][0] * p[4][2] + p[4][3] * p[4][1] * p[4][2])
+                                                       for p in sel) / max(n, 1)),
+             "mfma_issue_frac": round((3.0 if b3 else 1.0) * achieved / peak, 4),
+             "launches_per_step": n // max(prof_steps, 1), "avg_launch_ms": round(avg_ms, 4),
+             "ms_per_step_by_kernel": {str(k): round(v / table_steps, 3) for k, v in sorted(by_kern.items(), key=lambda kv: -kv[1])},
+             "algorithmic_tflops_by_kernel": {str(k): round(fl_kern[k] / (by_kern[k] * 1e-3) / 1e12, 1) for k in sorted(by_kern, key=lambda k: -by_kern[k])}}
+    return entry, dom, pmc_key, sum(kernel_ms), sum(all_ms), limited, fl_kern
+
+
+def pmc_traffic(math, pmc_key):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this command (rocprofv3 counters cannot be
+    collected from inside the run).  The profile records a hash of csrc/ (tools/diag/pmc_to_json.py): when the kernels have changed
+    since, the figure is stale and `traffic` is null -- never a number from other code."""
+    from radardistill_amd import native
+    cur = native.csrc_sha()
+    for rnd in ("round3", "round2", "round1"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm_traffic_{math}.json")
+        try:
+            pm = json.load(open(path))
+        except Exception:
+            continue
+        try:
+            val = next(v["hbm_bytes_per_launch_corrected"] for k, v in pm["kernels"].items() if pmc_key in k)
+        except StopIteration:
+            continue
+        src = os.path.relpath(path, ROOT)
+        if pm.get("csrc_sha") != cur:
+            return None, f"{src} was collected from other kernel sources (csrc hash {str(pm.get('csrc_sha'))[:12]} != {cur[:12]}): stale, not reported"
+        return val, src
+    return None, "no PMC pass committed for this arithmetic mode"
+
+
 def cu_limited():
     """Instantiation tags whose launches the library restricts to a share of the CUs (conv_wgrad_d3.hip, RD_WGRAD_D3_RES)."""
     from radardistill_amd import autograd as A, kernels as K
@@ -162,15 +304,36 @@ def main():
     args = parse()
     if args.other_math_steps < 0:
         args.other_math_steps = args.steps
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (no GPU call has been made yet)
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     from radardistill_amd import dist as D
     world, rank, local_rank = D.env_world()
+    check_world(args.gpus, world)
+    backend = os.environ.get("RD_DIST_BACKEND", "nccl")
+    if os.environ.get("RD_BENCH_DRY_RUN"):
+        # launcher / rank bookkeeping rehearsal without a GPU (tests/test_cpu_host.py): rendezvous, barrier, max-over-ranks, one line
+        D.init_distributed(backend="gloo")
+        D.barrier()
+        dt = D.max_over_ranks(0.001 * (rank + 1))
+        if rank == 0:
+            print(json.dumps({"metric": "samples/sec", "dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "max_over_ranks_s": dt, "global_batch": args.batch * world}), flush=True)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: {world} ranks but {torch.cuda.device_count()} visible GPU(s): RCCL needs one GPU per rank "
+                         "(RD_DIST_BACKEND=gloo lets ranks share a GPU to rehearse the path)")
     dev_index = local_rank % torch.cuda.device_count()                # as tools/train.py:176 of the reference
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     # "nccl" is RCCL on ROCm.  RD_DIST_BACKEND=gloo lets two ranks share ONE GPU to rehearse the DDP path on a 1-GPU box
-    D.init_distributed(backend=os.environ.get("RD_DIST_BACKEND", "nccl"), device=device)
+    D.init_distributed(backend=backend, device=device)
     from radardistill_amd import kernels as K
     from radardistill_amd import native
     from radardistill_amd.pcdet.models import model_fn_decorator
@@ -283,19 +446,48 @@ def main():
         iso_bn, K.BN_PROFILE = K.BN_PROFILE, None
         os.environ["RD_TEACHER_STREAM"] = prev_env
         A.WGRAD_STREAM[0] = prev_w
-    # the same step in the other arithmetic mode, for reference (outside the timed region)
+    # the same step in the other arithmetic mode (outside the timed region), measured the same way: barrier-bracketed steps, max over
+    # ranks, and HIP events on its dominant MFMA kernel -- with --math bf16x3 this leg is the exact-fp32 result (`roofline_f32`)
     other = None
+    o_rank = o_timed = None
+    o_hooked = 0
     if args.other_math_steps > 0:
         om = "f32" if args.math == "bf16x3" else "bf16x3"
         K.set_conv_math(om)
-        it0 = args.warmup + args.steps
+        it0 = args.warmup + args.steps + 2
+        hooks = not os.environ.get("RD_BENCH_NO_HOOKS")
+        K.prefill_event_pool(min(30000, 900 * 2 + 260 * (args.other_math_steps + 1)))
+        if hooks:
+            K.CONV_PROFILE, K.WGRAD_PROFILE = [], []          # ranking step of this mode: events on every MFMA launch, untimed
         step(it0)
+        torch.cuda.synchronize()
+        if hooks:
+            o_rank, K.CONV_PROFILE, K.WGRAD_PROFILE = K.CONV_PROFILE + K.WGRAD_PROFILE, None, None
+            oby = {}
+            for a_, b_, _, _, shp in o_rank:
+                oby[shp[5]] = oby.get(shp[5], 0.0) + a_.elapsed_time(b_)
+            for tag in cu_limited():
+                oby.pop(tag, None)
+            K.PROFILE_TAGS = {max(oby, key=lambda k: oby[k])} if oby else None
+        oprof, owprof = [], []
+        o_every = 2 if args.other_math_steps >= 6 else 1
         barrier()
         t1 = time.perf_counter()
         for it in range(it0 + 1, it0 + 1 + args.other_math_steps):
+            on = hooks and K.PROFILE_TAGS is not None and (it - it0 - 1) % o_every == 0
+            K.CONV_PROFILE, K.WGRAD_PROFILE = (oprof, owprof) if on else (None, None)
+            if on:
+                o_hooked += 1
+                if str(next(iter(K.PROFILE_TAGS))).startswith("wgrad"):
+                    K.CONV_PROFILE = None
+                else:
+                    K.WGRAD_PROFILE = None
             step(it)
         barrier()
         odt = D.max_over_ranks(time.perf_counter() - t1, device)
+        K.PROFILE_TAGS = None
+        K.CONV_PROFILE = K.WGRAD_PROFILE = None
+        o_timed = oprof + owprof
         K.set_conv_math(args.math)
         other = {"conv_math": om, "value": round(args.batch * world * args.other_math_steps / odt, 3), "unit": "samples/sec",
                  "ms_per_step": round(odt / args.other_math_steps * 1e3, 3), "steps": args.other_math_steps}
@@ -319,87 +511,42 @@ def main():
         # every MFMA convolution launch of the timed region: forward, data gradient (CONV_PROFILE) and weight gradient (WGRAD_PROFILE),
         # each tagged with the instantiation the C dispatch picks (kernels._kernel_tag / conv_wgrad)
         timed = list(prof) + list(wprof or [])
-        prof = rank_prof if rank_prof is not None else timed          # the table over ALL instantiations: ranking step, or the timed region
+        table = rank_prof if rank_prof is not None else timed          # the table over ALL instantiations: ranking step, or the timed region
         rank_steps = 1 if rank_prof is not None else prof_steps
-        all_ms = [a.elapsed_time(b) for a, b, _, _, _ in prof]
-        all_flops = [(f if pairs is None else float(pairs.item()) * f) for _, _, pairs, f, _ in prof]
         if os.environ.get("RD_BENCH_SHAPES"):
             agg = {}
-            for ms, fl, (_, _, _, _, shape) in zip(all_ms, all_flops, prof):
-                a = agg.setdefault(shape, [0, 0.0, 0.0]); a[0] += 1; a[1] += ms; a[2] += fl
+            for p_ in table:
+                a = agg.setdefault(p_[4], [0, 0.0, 0.0]); a[0] += 1; a[1] += p_[0].elapsed_time(p_[1]); a[2] += _flops_of(p_)
             for shape, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 print(f"[shape in_rows,Cin,Cout,taps,mode,kernel={shape}] launches/step {n / rank_steps:.1f} ms/step {ms / rank_steps:.3f} "
                       f"TF/s {fl / (ms * 1e-3) / 1e12:.1f}", file=sys.stderr)
         # roofline of the DOMINANT kernel = the MFMA instantiation with the largest summed time, weight gradients included.
-        # achieved = ALGORITHMIC flops (dense 2 k^2 Cin Cout rows, sparse 2 pairs Cin Cout) / launch duration, over its
-        # launches inside the timed region.
-        b3 = args.math == "bf16x3"
-        by_kern, fl_kern, n_kern = {}, {}, {}
-        for i, p in enumerate(prof):
-            tag = p[4][5]
-            by_kern[tag] = by_kern.get(tag, 0.0) + all_ms[i]
-            fl_kern[tag] = fl_kern.get(tag, 0.0) + all_flops[i]
-            n_kern[tag] = n_kern.get(tag, 0) + 1
         # Kernels the library deliberately keeps to a share of the chip (the halo weight-gradient kernel runs on <= 80 CUs of its side
         # stream so that the main stream can start work beside it: 19.4 -> 18.7 ms per step) have launch durations set by that share,
         # not by their code; they are listed under `cu_limited_kernels` and the dominant kernel is chosen among the others.
-        limited = {t: by_kern[t] for t in cu_limited() if t in by_kern}
-        ranked = {k: v for k, v in by_kern.items() if k not in limited} or by_kern
-        dom = max(ranked, key=lambda k: ranked[k]) if ranked else 128
-        sel = [p for p in timed if p[4][5] == dom]
-        kernel_ms = [a.elapsed_time(b) for a, b, _, _, _ in sel]
-        flops = [(f if pairs is None else float(pairs.item()) * f) for _, _, pairs, f, _ in sel]
-        n_launch = len(sel)
-        avg_ms = sum(kernel_ms) / max(n_launch, 1)
-        achieved = (sum(flops) / max(n_launch, 1)) / (avg_ms * 1e-3) / 1e12 if n_launch else 0.0
+        step_ms = dt / args.steps * 1e3
+        roof, dom, pmc_key, dom_ms, all_ms_sum, limited, fl_kern = mfma_roofline(timed, table, rank_steps, prof_steps, args.math, cu_limited())
+        peak = roof["peak"]
         iso = None
         if iso_prof:
-            isel = [p for p in iso_prof if p[4][5] == dom]
+            isel = [p_ for p_ in iso_prof if p_[4][5] == dom]
             if isel:
                 ims = sum(a.elapsed_time(b) for a, b, _, _, _ in isel) / len(isel)
-                ifl = sum((f if pairs is None else float(pairs.item()) * f) for _, _, pairs, f, _ in isel) / len(isel)
+                ifl = sum(_flops_of(p_) for p_ in isel) / len(isel)
                 iso = (ims, ifl / (ims * 1e-3) / 1e12)
-        arith = ("fp32 operands split to bf16 hi+lo, 3 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate" if b3 else
-                 "exact fp32 on v_mfma_f32_32x32x2_f32")
-        names = {
-            "d3_128": ("k_conv_d3_b3<8,16,128> (dense stride-1 3x3 conv, forward and data gradient: halo-staged 8x16-pixel tile)", "k_conv_d3_b3<8, 16, 128"),
-            "d3_16x64": ("k_conv_d3_b3<8,16,64> (dense stride-1 3x3 conv, halo-staged 8x16-pixel x 64-channel tile: the 8192-row maps)", "k_conv_d3_b3<8, 16, 64"),
-            "d3_64": ("k_conv_d3_b3<8,8,64> (dense stride-1 3x3 conv, halo-staged 8x8-pixel x 64-channel tile)", "k_conv_d3_b3<8, 8, 64"),
-            128: ("k_conv_igemm%s<128,128> (gathered implicit-GEMM conv: sparse / 1x1 / strided / transposed, forward and data gradient)" % ("_b3" if b3 else ""),
-                  "k_conv_igemm_b3<128, 128" if b3 else "k_conv_igemm<128, 128"),
-            64: ("k_conv_igemm%s<64,64> (gathered implicit-GEMM conv, 64x64 tiles)" % ("_b3" if b3 else ""), "k_conv_igemm_b3<64, 64" if b3 else "k_conv_igemm<64, 64"),
-            "64x128_table": ("k_conv_igemm_b3<64,128,..,table> (gathered implicit-GEMM conv of the sparse layers, neighbour-table geometry, 64-row x "
-                             "128-channel tiles)", "k_conv_igemm_b3<64, 128, false, false, 2"),
-            "64x128_dense": ("k_conv_igemm_b3<64,128,..,dense> (stride-2 transposed convs, one output line per tile)", "k_conv_igemm_b3<64, 128, false, false, 3"),
-            "64_table": ("k_conv_igemm_b3<64,64,..,table> (gathered implicit-GEMM conv, sparse layers, 64x64 tiles)", "k_conv_igemm_b3<64, 64, false, false, 2"),
-            "64_dense": ("k_conv_igemm_b3<64,64,..,dense> (1x1 projections, strided convs: dense geometry, 64x64 tiles)", "k_conv_igemm_b3<64, 64, false, false, 3"),
-            "128_table": ("k_conv_igemm_b3<128,128,..,table> (gathered implicit-GEMM conv, large sparse layers)", "k_conv_igemm_b3<128, 128, false, false, 2"),
-            "128_dense": ("k_conv_igemm_b3<128,128,..,dense> (large dense-geometry layers)", "k_conv_igemm_b3<128, 128, false, false, 3"),
-            "128x64_table": ("k_conv_igemm_b3<128,64,..,table> (large sparse layers with <= 64 output channels)", "k_conv_igemm_b3<128, 64, false, false, 2"),
-            "128x64_dense": ("k_conv_igemm_b3<128,64,..,dense>", "k_conv_igemm_b3<128, 64, false, false, 3"),
-            "wgrad_d3": ("k_conv_wgrad_d3_b3 (weight gradient of dense stride-1 3x3 convs: 8x8-pixel grad_out tile + 10x10 input halo staged once, "
-                         "all 9 taps per staged tile, ds_read_b64_tr_b16 fragments, 8 waves x (32 co x 32 ci x 9 taps))", "k_conv_wgrad_d3_b3"),
-            "wgrad_b3_128": ("k_conv_wgrad_tr_b3<128> (gathered weight gradient GEMM: M = Cout tile 128, N = Cin tile 128 of one tap, K = rows; "
-                             "row-major LDS images read with ds_read_b64_tr_b16; row chunks combined with fp32 atomics)", "k_conv_wgrad_tr_b3<128"),
-            "wgrad_b3_64": ("k_conv_wgrad_tr_b3<64> (gathered weight gradient GEMM, Cin tile 64)", "k_conv_wgrad_tr_b3<64"),
-            "wgrad_b3_deform_128": ("k_conv_wgrad_b3<true,128> (DCNv2 weight gradient: input rows blended from 4 bilinear corners while staged)", "k_conv_wgrad_b3<true, 128"),
-            "wgrad_f32_128": ("k_conv_wgrad<false,128> (weight gradient GEMM, exact fp32 MFMA)", "k_conv_wgrad<false, 128"),
-            "wgrad_f32_64": ("k_conv_wgrad<false,64> (weight gradient GEMM, exact fp32 MFMA, Cin tile 64)", "k_conv_wgrad<false, 64"),
-            "wgrad_f32_deform_128": ("k_conv_wgrad<true,128> (DCNv2 weight gradient, exact fp32 MFMA)", "k_conv_wgrad<true, 128"),
-            "wgrad_f32_deform_64": ("k_conv_wgrad<true,64> (DCNv2 weight gradient, exact fp32 MFMA)", "k_conv_wgrad<true, 64"),
-        }
-        kname, pmc_key = names.get(dom, (str(dom), str(dom)))
-        peak = PEAK_BF16_MFMA_TFLOPS if b3 else PEAK_F32_MFMA_TFLOPS
-        issue = 3.0 if b3 else 1.0        # bf16x3: every algorithmic multiply-add is three bf16 MFMA products
-        traffic = None          # HBM bytes per launch from the committed PMC passes of this command (cannot be collected live inside bench.py)
-        for rnd in ("round2", "round1"):
-            try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm_traffic_{args.math}.json")))["kernels"]
-                traffic = next(v["hbm_bytes_per_launch_corrected"] for k, v in pm.items() if pmc_key in k)
-                break
-            except Exception:
-                pass
-        step_ms = dt / args.steps * 1e3
+        roof["traffic"], roof["traffic_source"] = pmc_traffic(args.math, pmc_key)
+        roof["isolated"] = None if iso is None else {
+            "note": "same launches in 2 extra steps with the stream overlaps (teacher || student, wgrad || dgrad) off: in the timed region a "
+                    "launch shares the GPU with the other streams' kernels, which lengthens it while shortening the step",
+            "avg_launch_ms": round(iso[0], 4), "achieved": round(iso[1], 3), "frac": round(iso[1] / peak, 4)}
+        roof["measured"] = roofline_note
+        roof["cu_limited_kernels"] = {t: {"max_cus": K.WGRAD_D3_MAX_CUS, "of": 256, "ms_per_step": round(v / rank_steps, 3),
+                                          "algorithmic_tflops": round(fl_kern[t] / (v * 1e-3) / 1e12, 1),
+                                          "note": "side stream, overlapped with the main stream; launched on a share of the chip by design, "
+                                                  "so its launch duration reflects that share"} for t, v in limited.items()}
+        roof["time_share_of_step"] = round(dom_ms / prof_steps / step_ms, 4)
+        roof["all_mfma_conv_share_of_step"] = round(all_ms_sum / rank_steps / step_ms, 4)
+        b3 = args.math == "bf16x3"
         out = {
             "metric": "samples/sec", "value": round(samples / dt, 3), "unit": "samples/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(step_ms, 3), "higher_is_better": True, "scaling": "weak",
@@ -409,31 +556,19 @@ def main():
                        "bev": f"{args.grid}x{args.grid}", "pillar_m": 0.2, "lidar_pts": 35000, "radar_pts": 2000, "boxes": 30,
                        "conv_math": args.math, "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}" + ("" if world == 1 else ("/ddp" if os.environ.get("RD_DDP", "flat") == "torch" else "/flat-allreduce")) + ("+sync_bn" if args.sync_bn else ""),
                        "teacher_head": "computed (unused by the loss, as in the reference)", "final_loss": last_loss},
-            "roofline": {"bound": "mfma", "kernel": kname + "; " + arith,
-                         "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "flops": "algorithmic (SURVEY 8(d)): dense 2*k*k*Cin*Cout*rows, sparse 2*pairs*Cin*Cout",
-                         "algorithmic_flops_per_launch": round(sum(flops) / max(n_launch, 1)),
-                         # what `traffic` (PMC, all launches of this kernel in the profiled command) compares with: input + output +
-                         # weights touched once, averaged over the same launches (shape tuple = rows_in, Cin, Cout, taps)
-                         "algorithmic_bytes_per_launch": round(sum(4.0 * (p[4][0] * p[4][1] + p[4][0] * p[4][2] + p[4][3] * p[4][1] * p[4][2])
-                                                                   for p in sel) / max(n_launch, 1)),
-                         "mfma_issue_frac": round(issue * achieved / peak, 4),
-                         "isolated": None if iso is None else {
-                             "note": "same launches in 2 extra steps with the stream overlaps (teacher || student, wgrad || dgrad) off: in the timed region a "
-                                     "launch shares the GPU with the other streams' kernels, which lengthens it while shortening the step",
-                             "avg_launch_ms": round(iso[0], 4), "achieved": round(iso[1], 3), "frac": round(iso[1] / peak, 4)},
-                         "launches_per_step": n_launch // max(prof_steps, 1), "measured": roofline_note, "avg_launch_ms": round(avg_ms, 4),
-                         "ms_per_step_by_kernel": {str(k): round(v / rank_steps, 3) for k, v in sorted(by_kern.items(), key=lambda kv: -kv[1])},
-                         "algorithmic_tflops_by_kernel": {str(k): round(fl_kern[k] / (by_kern[k] * 1e-3) / 1e12, 1) for k in sorted(by_kern, key=lambda k: -by_kern[k])},
-                         "cu_limited_kernels": {t: {"max_cus": K.WGRAD_D3_MAX_CUS, "of": 256, "ms_per_step": round(v / rank_steps, 3),
-                                                    "algorithmic_tflops": round(fl_kern[t] / (v * 1e-3) / 1e12, 1),
-                                                    "note": "side stream, overlapped with the main stream; launched on a share of the chip by design, "
-                                                            "so its launch duration reflects that share (RD_WGRAD_D3_RES=256 gives it the whole chip: "
-                                                            "0.114 ms per launch alone, +0.7 ms per step)"} for t, v in limited.items()},
-                         "time_share_of_step": round(sum(kernel_ms) / prof_steps / step_ms, 4),
-                         "all_mfma_conv_share_of_step": round(sum(all_ms) / rank_steps / step_ms, 4)},
+            "roofline": roof,
         }
+        # the strict-precision result of the same run: the exact-fp32 leg's dominant kernel against the fp32 MFMA peak
+        if other is not None and o_rank:
+            om = other["conv_math"]
+            oroof, odom, okey, odom_ms, oall_ms, _, _ = mfma_roofline(o_timed, o_rank, 1, max(o_hooked, 1), om, cu_limited())
+            oroof["traffic"], oroof["traffic_source"] = pmc_traffic(om, okey)
+            oroof["samples_per_sec"], oroof["ms_per_step"] = other["value"], other["ms_per_step"]
+            oroof["measured"] = (f"HIP events around every launch of this kernel in {o_hooked} of the {other['steps']} steps of the {om} leg "
+                                 "(timed after the headline region of the same run, same barrier / max-over-ranks bracket); the per-kernel "
+                                 "table comes from the leg's untimed first step with events on every MFMA launch")
+            oroof["time_share_of_step"] = round(odom_ms / max(o_hooked, 1) / other["ms_per_step"], 4)
+            out["roofline_" + om] = oroof
         # HBM side of the metric ("HBM GB/s vs peak"): the streaming train-mode BatchNorm forward (normalise + affine + residual + ReLU,
         # one launch per layer), algorithmic bytes = x (+ residual) read once, y written once; launches of >= 16 MB only (smaller maps
         # are launch-latency bound and L2 / Infinity-Cache resident).

@@ -370,16 +370,25 @@ int rd_pack_grads(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, i
  * the norm is not finite; rd_adam_step subtracts it from `step` (a step GradScaler skips is not an Adam step). */
 int rd_grad_norm(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, float max_norm, float *out2, float *ws,
                  int64_t ws_bytes, const float *flat_grad, float grad_scale, const float *inv_loss_scale_dev, int32_t *overflow_count_dev,
-                 void *stream);
+                 const float *present_dev, void *stream);
+/* Data parallelism: which tensors take part in this step must be the same answer on every rank (torch's DistributedDataParallel
+ * raises when a parameter is unused on one rank only; deciding from the rank-local `grad` pointer would give the ranks different
+ * norms, clip coefficients and Adam step counts).  rd_grad_presence writes present[t] = 1.0 / 0.0 from the table's grad pointers; the
+ * caller all-reduces it (MAX) over the ranks and passes it as present_dev (with flat_grad) to rd_grad_norm / rd_adam_step, which
+ * then take a tensor's gradient from the flat buffer whenever ANY rank had one (absent ranks packed zeros).  present_dev = NULL: the
+ * decision is the local pointer (single process). */
+int rd_grad_presence(const rd_opt_tensor *tensors_dev, int n_tensors, float *present_dev, void *stream);
 /* step = 1-based count of optimizer steps (bias correction).  clip_dev may be NULL (no clipping) or out2 of rd_grad_norm.
  * A tensor whose `grad` is NULL sits the step out as in torch.optim.Adam (only the decoupled decay p *= 1 - wd*lr of
- * OptimWrapper.step touches it; rd_grad_norm ignores it, rd_pack_grads packs zeros); skipped_dev (NULL = all zero) holds per tensor
- * how many steps it sat out so far, so that its own bias-correction count is step - skipped[t].  Hyper-parameters are doubles: the
+ * OptimWrapper.step touches it; rd_grad_norm ignores it, rd_pack_grads packs zeros); skipped_dev (NULL = all zero, nothing counted)
+ * holds per tensor how many steps it sat out so far, so that its own bias-correction count is step - skipped[t]; the launch itself
+ * adds 1 for every tensor that sits THIS step out (ABI 3: the counters are device-owned).  Hyper-parameters are doubles: the
  * reference forms 1 - wd*lr, lr / (1 - beta1^t), sqrt(1 - beta2^t) in Python floats before they meet fp32 tensors.
  * skip_nonfinite = 1 (GradScaler.step): when clip_dev[0] (the gradient norm) is not finite the launch changes nothing. */
 int rd_adam_step(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, double lr, double beta1, double beta2, double eps,
-                 double weight_decay, int step, const int32_t *skipped_dev, const float *clip_dev, const float *flat_grad, float grad_scale,
-                 const float *inv_loss_scale_dev, int skip_nonfinite, const int32_t *overflow_count_dev, void *stream);
+                 double weight_decay, int step, int32_t *skipped_dev, const float *clip_dev, const float *flat_grad, float grad_scale,
+                 const float *inv_loss_scale_dev, int skip_nonfinite, const int32_t *overflow_count_dev, const float *present_dev,
+                 void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * J. Depthwise KxK convolution on channels-last maps (ConvNeXt dwconv 7x7, groups = C, padding K/2).  Replaces cuDNN's

@@ -24,8 +24,15 @@ _WEIGHTS_EPOCH = [0]
 _LAYOUT_CACHE = {}
 
 
-def bump_weights_epoch():
+_FROZEN_EPOCH = [-1]          # frozen parameters (the teacher) only change through torch (`_version`) -- or through a raw write that says so
+
+
+def bump_weights_epoch(frozen=False):
+    """frozen=True: frozen parameters / buffers were written behind torch's back as well (dist.broadcast_parameters copies through
+    `.data`): their cached layouts, split operands and folded BatchNorm coefficients are invalidated too."""
     _WEIGHTS_EPOCH[0] += 1
+    if frozen:
+        _FROZEN_EPOCH[0] -= 1
 
 
 class _ZeroArena:
@@ -157,7 +164,7 @@ def kernel_weight(param, Cout, Cin, taps, kind, flip=False):
     if not param.is_leaf or CAPTURING[0]:         # a per-step tensor (e.g. the concatenated head-branch weights): nothing to cache on;
         return K.weight_layout(src, Cout, Cin, taps, kind, flip)      # under capture: converted by a node of the graph, every replay
     key = (id(param), kind, flip)
-    ver = (param._version, _WEIGHTS_EPOCH[0] if param.requires_grad else -1, param.data_ptr())
+    ver = (param._version, _WEIGHTS_EPOCH[0] if param.requires_grad else _FROZEN_EPOCH[0], param.data_ptr())
     hit = _LAYOUT_CACHE.get(key)
     if hit is not None and hit[0] == ver and hit[2]() is param:      # the weakref guards against id() reuse after a model is freed
         return hit[1]
@@ -182,7 +189,7 @@ def kernel_weight_split(param, wk, Cout, Cin, taps, kind2=False):
     if not param.is_leaf:
         return make()
     key = (id(param), kind2)
-    ver = (param._version, _WEIGHTS_EPOCH[0] if param.requires_grad else -1, param.data_ptr(), Cout, Cin, taps)
+    ver = (param._version, _WEIGHTS_EPOCH[0] if param.requires_grad else _FROZEN_EPOCH[0], param.data_ptr(), Cout, Cin, taps)
     hit = _SPLIT_W_CACHE.get(key)
     if hit is not None and hit[0] == ver and hit[2]() is param:
         return hit[1]
@@ -217,7 +224,7 @@ class _OperandCache:
 
     @staticmethod
     def _ver(param):
-        return (param._version, _WEIGHTS_EPOCH[0] if param.requires_grad else -1, param.data_ptr())
+        return (param._version, _WEIGHTS_EPOCH[0] if param.requires_grad else _FROZEN_EPOCH[0], param.data_ptr())
 
     def get(self, param, Cout, Cin, taps, kind):
         key = (id(param), kind)
@@ -453,7 +460,15 @@ DEFER_LAYOUT = [os.environ.get("RD_DEFER_LAYOUT", "1") != "0"]
 
 
 def _defer_layout_ok(param):
-    return DEFER_LAYOUT[0] and WGRAD_STREAM[0] and param.is_cuda and _side_ok(param)
+    """Deferral hands autograd a gradient tensor that is still EMPTY until the pass ends, so nothing may read or combine it before
+    then: not a second use of the same weight in this graph (the engine would sum two empty tensors and both jobs would fill one
+    destination -- the later occurrences are laid out immediately instead), not a tensor hook on the parameter (it would see, scale
+    or clip garbage)."""
+    if not (DEFER_LAYOUT[0] and WGRAD_STREAM[0] and param.is_cuda and _side_ok(param)):
+        return False
+    if getattr(param, "_backward_hooks", None):
+        return False
+    return all(j[2] is not param for j in _DEFERRED_LAYOUT)
 
 
 def _flush_deferred_layouts(only_accumulated=False):
@@ -468,13 +483,21 @@ def _flush_deferred_layouts(only_accumulated=False):
     for i in range(0, len(jobs), 96):
         part = jobs[i:i + 96]
         arr = (LayoutJob * len(part))()
-        for k, (src, dst_ptr, param, Cout, Cin, taps, kind) in enumerate(part):
+        n = 0
+        for (src, dst_ref, param, Cout, Cin, taps, kind) in part:
             # where the gradient ended up: AccumulateGrad normally keeps the very tensor backward returned (then .grad IS the deferred
-            # destination); had it cloned instead (an extra reference, a layout mismatch), the clone is what must be filled
+            # destination); had it cloned instead (an extra reference, a layout mismatch), the clone is what must be filled.  Without a
+            # .grad the destination is only written while it is still alive (weak reference) -- never through a stale address.
             g = param.grad
-            arr[k].src, arr[k].dst = src.data_ptr(), (g.data_ptr() if g is not None else dst_ptr)
-            arr[k].Cout, arr[k].Cin, arr[k].taps, arr[k].kind = Cout, Cin, taps, kind
-        K.weight_layout_multi(arr, len(part))
+            if g is None:
+                g = dst_ref()
+                if g is None:
+                    continue
+            arr[n].src, arr[n].dst = src.data_ptr(), g.data_ptr()
+            arr[n].Cout, arr[n].Cin, arr[n].taps, arr[n].kind = Cout, Cin, taps, kind
+            n += 1
+        if n:
+            K.weight_layout_multi(arr, n)
 
 
 def defer_weight_layout(gwk, param, Cout, Cin, taps, kind):
@@ -482,7 +505,7 @@ def defer_weight_layout(gwk, param, Cout, Cin, taps, kind):
     Called on the weight-gradient stream (inside param_grad_stream) or, without it, on the main stream.  No reference to the
     returned tensor is kept here: AccumulateGrad only adopts a gradient nobody else holds (it clones otherwise)."""
     dst = torch.empty(tuple(param.shape), dtype=torch.float32, device=gwk.device)
-    _DEFERRED_LAYOUT.append((gwk, dst.data_ptr(), param, Cout, Cin, taps, kind))
+    _DEFERRED_LAYOUT.append((gwk, weakref.ref(dst), param, Cout, Cin, taps, kind))
     if not _DEFER_QUEUED[0]:
         _DEFER_QUEUED[0] = True
         dev = gwk.device
@@ -819,7 +842,7 @@ _BN_FOLD_CACHE = {}
 def bn_eval_scale_shift(bn):
     """Folded eval-mode BatchNorm: y = x*scale + shift.  Cached per module while its parameters / running statistics are
     unchanged (the frozen teacher: computed once instead of 4 small launches per layer per step)."""
-    ver = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, _WEIGHTS_EPOCH[0] if bn.weight.requires_grad else -1,
+    ver = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, _WEIGHTS_EPOCH[0] if bn.weight.requires_grad else _FROZEN_EPOCH[0],
            bn.weight.data_ptr(), bn.running_var.data_ptr())
     hit = _BN_FOLD_CACHE.get(id(bn))
     if hit is not None and hit[0] == ver and hit[3]() is bn:

@@ -20,7 +20,7 @@ namespace rd { int g_deterministic = 0; }
 extern "C" int rd_set_deterministic(int on) { rd::g_deterministic = on ? 1 : 0; return RD_OK; }
 extern "C" int rd_get_deterministic(void) { return rd::g_deterministic; }
 extern "C" const char *rd_last_error(void) { return rd::g_err; }
-extern "C" int rd_abi_version(void) { return 2; }
+extern "C" int rd_abi_version(void) { return 3; }
 // Fork: `to` waits for everything enqueued on `from` so far.  One library-owned event per waiting stream, re-recorded on every call (a
 // wait captures the event's state when it is enqueued, so re-recording afterwards is safe).  Exists because the weight-gradient side
 // stream forks ~90 times per backward pass: one C call instead of torch's Event.record + Stream.wait_event (~3 us of Python each time).

@@ -20,17 +20,30 @@ __device__ __forceinline__ const float *grad_ptr(const rd_opt_tensor *tensors, c
     return flat ? flat + (t.exp_avg - tensors[0].exp_avg) : t.grad;
 }
 
+// Does tensor `tid` take part in this step?  Single process: it has a gradient pointer.  With a flat all-reduced buffer the answer
+// must be the SAME on every rank (a branch unused by one rank's batch has p.grad None there only; deciding from the rank-local
+// pointer would give the ranks different norms, clip coefficients and Adam step counts): `present` holds, per tensor, the MAX over
+// ranks of "has a gradient" (rd_grad_presence + all-reduce), and the values come from the flat buffer, where absent ranks packed zeros.
+__device__ __forceinline__ bool takes_part(const rd_opt_tensor &t, int tid, const float *flat, const float *present) {
+    return (flat && present) ? present[tid] > 0.f : t.grad != nullptr;
+}
+
+__global__ void k_grad_presence(const rd_opt_tensor *__restrict__ tensors, int n, float *present) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) present[i] = tensors[i].grad ? 1.f : 0.f;
+}
+
 // inv_loss_scale (device scalar or NULL): mixed-precision loss scaling (torch.cuda.amp.GradScaler, train_utils.py:23,57-64): the
 // gradients in memory are S times too large; the norm and the Adam update use g / S without a separate unscale pass.
 __global__ __launch_bounds__(256) void k_gradnorm_partial(const rd_opt_tensor *__restrict__ tensors, const int2 *__restrict__ chunks, int n_chunks,
                                                           const float *__restrict__ flat, float grad_scale, const float *__restrict__ inv_loss_scale,
-                                                          float *partial) {
+                                                          const float *__restrict__ present, float *partial) {
     __shared__ float red[4];
     if (inv_loss_scale) grad_scale *= inv_loss_scale[0];
     const int2 ch = chunks[blockIdx.x];
     const rd_opt_tensor t = tensors[ch.x];
     const float *g = grad_ptr(tensors, t, flat) + ch.y;
-    const int64_t n = t.grad ? min((int64_t)OPT_CHUNK, t.numel - ch.y) : 0;       // no gradient this step: torch's clip skips the tensor
+    const int64_t n = takes_part(t, ch.x, flat, present) ? min((int64_t)OPT_CHUNK, t.numel - ch.y) : 0;       // no gradient this step: torch's clip skips the tensor
     float s = 0.f;
     for (int64_t i = threadIdx.x; i < n; i += 256) {
         float v = g[i] * grad_scale;
@@ -65,13 +78,14 @@ __global__ void k_gradnorm_final(const float *partial, int n, float max_norm, fl
 
 // A tensor whose gradient pointer is NULL is only decayed (OptimWrapper.step decays every trainable parameter, torch.optim.Adam
 // skips parameters without a gradient: no moment update, no step count).  `skipped[t]` = how many optimizer steps tensor t sat out,
-// so its own Adam step count is step - skipped[t]; with skipped == NULL every tensor is at `step` and the bias corrections come
-// precomputed (in double) from the host.
+// so its own Adam step count is step - skipped[t]; the kernel itself counts a sat-out step (device-owned, so that the data-parallel
+// case needs no host read of the group-wide presence mask); with skipped == NULL every tensor is at `step` and the bias corrections
+// come precomputed (in double) from the host.
 __global__ __launch_bounds__(256) void k_adam(const rd_opt_tensor *__restrict__ tensors, const int2 *__restrict__ chunks, double lr, float beta1,
                                               float beta2, float eps, float decay, float step_size0, float bc2_sqrt0, double beta1d, double beta2d,
-                                              int step, const int32_t *__restrict__ skipped, const float *__restrict__ clip,
+                                              int step, int32_t *__restrict__ skipped, const float *__restrict__ clip,
                                               const float *__restrict__ flat, float grad_scale, const float *__restrict__ inv_loss_scale,
-                                              int skip_nonfinite, const int32_t *__restrict__ overflow_count) {
+                                              int skip_nonfinite, const int32_t *__restrict__ overflow_count, const float *__restrict__ present) {
     __shared__ float sh[2];
     // GradScaler.step: an overflowed step (non-finite gradient norm) leaves parameters, moments and the decoupled decay untouched
     if (skip_nonfinite && clip && !isfinite(clip[0])) return;
@@ -80,8 +94,9 @@ __global__ __launch_bounds__(256) void k_adam(const rd_opt_tensor *__restrict__ 
     const rd_opt_tensor t = tensors[ch.x];
     const int64_t n = min((int64_t)OPT_CHUNK, t.numel - ch.y);
     float *p = t.param + ch.y;
-    if (t.grad == nullptr) {
+    if (!takes_part(t, ch.x, flat, present)) {
         for (int64_t i = threadIdx.x; i < n; i += 256) p[i] *= decay;
+        if (skipped && ch.y == 0 && threadIdx.x == 0) skipped[ch.x] += 1;       // nobody reads skipped[ch.x] in a step the tensor sits out
         return;
     }
     float step_size = step_size0, bc2_sqrt = bc2_sqrt0;
@@ -167,20 +182,20 @@ extern "C" int rd_pack_grads(const rd_opt_tensor *tensors_dev, const int32_t *ch
 
 extern "C" int rd_grad_norm(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, float max_norm, float *out2,
                             float *ws, int64_t ws_bytes, const float *flat_grad, float grad_scale, const float *inv_loss_scale_dev,
-                            int32_t *overflow_count_dev, void *stream) {
+                            int32_t *overflow_count_dev, const float *present_dev, void *stream) {
     RD_REQUIRE(n_chunks >= 0 && ws_bytes >= (int64_t)n_chunks * 4, "rd_grad_norm: workspace too small");
     hipStream_t st = S(stream);
     if (n_chunks > 0)
         k_gradnorm_partial<<<n_chunks, 256, 0, st>>>(tensors_dev, reinterpret_cast<const int2 *>(chunks_dev), n_chunks, flat_grad, grad_scale,
-                                                     inv_loss_scale_dev, ws);
+                                                     inv_loss_scale_dev, present_dev, ws);
     k_gradnorm_final<<<1, 256, 0, st>>>(ws, n_chunks, max_norm, out2, overflow_count_dev);
     return check_launch("rd_grad_norm");
 }
 
 extern "C" int rd_adam_step(const rd_opt_tensor *tensors_dev, const int32_t *chunks_dev, int n_chunks, double lr, double beta1, double beta2,
-                            double eps, double weight_decay, int step, const int32_t *skipped_dev, const float *clip_dev,
+                            double eps, double weight_decay, int step, int32_t *skipped_dev, const float *clip_dev,
                             const float *flat_grad, float grad_scale, const float *inv_loss_scale_dev, int skip_nonfinite,
-                            const int32_t *overflow_count_dev, void *stream) {
+                            const int32_t *overflow_count_dev, const float *present_dev, void *stream) {
     RD_REQUIRE(!skip_nonfinite || clip_dev, "rd_adam_step: skip_nonfinite needs the norm of rd_grad_norm (clip_dev)");
     RD_REQUIRE(step >= 1, "rd_adam_step: step must be >= 1");
     if (n_chunks <= 0) return RD_OK;
@@ -188,8 +203,15 @@ extern "C" int rd_adam_step(const rd_opt_tensor *tensors_dev, const int32_t *chu
     const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
     k_adam<<<n_chunks, 256, 0, S(stream)>>>(tensors_dev, reinterpret_cast<const int2 *>(chunks_dev), lr, (float)beta1, (float)beta2, (float)eps,
                                             (float)(1.0 - weight_decay * lr), (float)(lr / bc1), (float)sqrt(bc2), beta1, beta2, step, skipped_dev,
-                                            clip_dev, flat_grad, grad_scale, inv_loss_scale_dev, skip_nonfinite, overflow_count_dev);
+                                            clip_dev, flat_grad, grad_scale, inv_loss_scale_dev, skip_nonfinite, overflow_count_dev, present_dev);
     return check_launch("rd_adam_step");
+}
+
+extern "C" int rd_grad_presence(const rd_opt_tensor *tensors_dev, int n_tensors, float *present_dev, void *stream) {
+    RD_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || (tensors_dev && present_dev)), "rd_grad_presence: NULL table or output");
+    if (n_tensors == 0) return RD_OK;
+    k_grad_presence<<<cdiv(n_tensors, 256), 256, 0, S(stream)>>>(tensors_dev, n_tensors, present_dev);
+    return check_launch("rd_grad_presence");
 }
 
 extern "C" int rd_opt_chunk_elems(void) { return OPT_CHUNK; }

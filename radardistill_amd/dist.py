@@ -55,6 +55,10 @@ def broadcast_parameters(model, src=0):
         for t in group:
             t.copy_(flat[off:off + t.numel()].view_as(t))
             off += t.numel()
+    # the copies above go through `.data` and move no version counter: every cache keyed on (param._version, weights epoch) -- kernel
+    # layouts, split operands, the concatenated CenterHead leaves, folded BatchNorm -- must see that the weights changed
+    from . import autograd as A
+    A.bump_weights_epoch(frozen=True)
 
 
 def data_parallel(model, optimizer, device_index=None, mode=None):
@@ -105,10 +109,21 @@ class GradBuckets:
     def reset(self):
         self.left = [hi - lo for lo, hi in self.ranges]
         self.launched = [False] * len(self.ranges)
+        self.seen = [False] * len(self.bucket_of)
+        self.dirty = set()                   # buckets that were launched and then received ANOTHER gradient (see ready)
 
     def ready(self, i):
-        """-> bucket index to launch now, or None."""
+        """-> bucket index to launch now, or None.
+        A parameter that reports a second time before reset() -- a second backward() before step(), i.e. gradient accumulation, or a
+        retry -- changes a gradient its bucket may already have sent: the bucket is marked dirty and open_buckets() hands it out
+        again, so that finish packs the ACCUMULATED p.grad and all-reduces the slice once more (the slice then holds the sum over
+        ranks of the accumulated gradients: correct, at the price of a second collective for that bucket)."""
         b = self.bucket_of[i]
+        if self.seen[i]:
+            if self.launched[b]:
+                self.dirty.add(b)
+            return None
+        self.seen[i] = True
         self.left[b] -= 1
         if self.left[b] == 0 and not self.launched[b]:
             self.launched[b] = True
@@ -116,9 +131,11 @@ class GradBuckets:
         return None
 
     def open_buckets(self):
-        out = [b for b, done in enumerate(self.launched) if not done]
+        """Buckets finish() still has to launch: the ones that never completed (parameters without a gradient) and the dirty ones."""
+        out = [b for b, done in enumerate(self.launched) if not done or b in self.dirty]
         for b in out:
             self.launched[b] = True
+        self.dirty.clear()
         return out
 
 

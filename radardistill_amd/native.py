@@ -121,8 +121,9 @@ SIGNATURES = {
     "rd_opt_chunk_elems": (c_int, []),
     "rd_pack_grads_list": (c_int, [_P, c_int, _P]),
     "rd_pack_grads": (c_int, [_P, _P, c_int, _P, _P]),
-    "rd_grad_norm": (c_int, [_P, _P, c_int, c_f32, _P, _P, c_i64, _P, c_f32, _P, _P, _P]),
-    "rd_adam_step": (c_int, [_P, _P, c_int, c_f64, c_f64, c_f64, c_f64, c_f64, c_int, _P, _P, _P, c_f32, _P, c_int, _P, _P]),
+    "rd_grad_norm": (c_int, [_P, _P, c_int, c_f32, _P, _P, c_i64, _P, c_f32, _P, _P, _P, _P]),
+    "rd_grad_presence": (c_int, [_P, c_int, _P, _P]),
+    "rd_adam_step": (c_int, [_P, _P, c_int, c_f64, c_f64, c_f64, c_f64, c_f64, c_int, _P, _P, _P, c_f32, _P, c_int, _P, _P, _P]),
     "rd_dwconv_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "rd_dwconv_wgrad_ws_bytes": (c_i64, [c_int, c_int, c_int, c_int, c_int]),
     "rd_dwconv_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_i64, _P]),
@@ -160,6 +161,17 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def csrc_sha():
+    """Hash of the kernel sources (csrc/*.hip, *.hpp): profiles/ summaries record it so that a counter figure is never quoted for
+    code it was not collected from (bench.py's roofline.traffic)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sources() + sorted(glob.glob(os.path.join(CSRC, "*.hpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def _stale():
     if not os.path.exists(SO_PATH):
         return True
@@ -180,8 +192,10 @@ def build(force=False, verbose=False):
     for src in sources():
         obj = os.path.join(CSRC, "obj", os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
+        # an object depends on its source, the public header and EVERY csrc/*.hpp (common.hpp, conv_common.hpp, iou3d_dev.hpp ...):
+        # cheaper than tracking includes per file, and an edited helper header can never relink a stale object
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(
-                os.path.getmtime(src), os.path.getmtime(HEADER), os.path.getmtime(os.path.join(CSRC, "common.hpp"))):
+                [os.path.getmtime(src), os.path.getmtime(HEADER)] + [os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.hpp"))]):
             continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
         if verbose:

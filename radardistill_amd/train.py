@@ -93,13 +93,23 @@ class FusedAdamOneCycle:
         self.ref_groups = [list(g) for g in ref_groups] if ref_groups is not None else [list(range(len(self.params))), []]
         if sorted(i for g in self.ref_groups for i in g) != list(range(len(self.params))):
             raise ValueError("ref_groups must number every trainable parameter exactly once")
-        # torch.optim.Adam keeps a step count PER PARAMETER and skips parameters whose gradient is None; `skipped[i]` = optimizer
-        # steps parameter i sat out (device copy refreshed only when it changes: never, in the distillation model)
-        self.skipped = np.zeros(len(self.params), dtype=np.int32)
-        self.skipped_dev = None
+        # torch.optim.Adam keeps a step count PER PARAMETER and skips parameters whose gradient is None; skipped_dev[i] = optimizer
+        # steps parameter i sat out.  Device-owned (rd_adam_step counts a sat-out step itself): under data parallelism "sat out" is a
+        # group-wide fact (the all-reduced presence mask) that the host never reads; `skipped` reads the counters back on demand
+        self.skipped_dev = torch.zeros(len(self.params), dtype=torch.int32, device=dev)
+        # steps skipped as a whole by loss-scaling overflow (AmpScaler): not Adam steps for any parameter; counted on the device by
+        # rd_grad_norm, owned here so that state_dict() / load_state_dict() keep every parameter's Adam `step` free of them
+        self.overflows = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._amp_used = False
+        self.present = None            # data parallelism: per-parameter "some rank has a gradient" mask, all-reduced every step
         self._static_cols = None
         self.flat_grad = None          # data parallelism: see enable_flat_allreduce()
         self.process_group = None
+
+    @property
+    def skipped(self):
+        """Per-parameter count of optimizer steps sat out (numpy; reads the device counters: checkpoint / test time only)."""
+        return self.skipped_dev.cpu().numpy()
 
     def enable_flat_allreduce(self, process_group=None, bucket_mb=None, overlap=None):
         """Data-parallel gradient exchange without DistributedDataParallel: the ~500 gradient tensors are packed into a flat fp32
@@ -115,6 +125,7 @@ class FusedAdamOneCycle:
         from .dist import GradBuckets
         n = int(self.offsets[-1])
         self.flat_grad = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
+        self.present = torch.zeros(len(self.params), dtype=torch.float32, device=self.params[0].device)
         self.process_group = process_group
         if overlap is None:
             overlap = os.environ.get("RD_DDP_OVERLAP", "1") != "0"
@@ -123,6 +134,7 @@ class FusedAdamOneCycle:
             mb = float(bucket_mb if bucket_mb is not None else os.environ.get("RD_DDP_BUCKET_MB", "25"))
             self.buckets = GradBuckets([p.numel() for p in self.params], int(mb * (1 << 20)))
             self._works = []
+            self._work_of = {}
             # high priority, like the training loop's own stream (use_training_stream): the collectives' few, long-lived workgroups
             # must not queue behind the compute streams' dispatches
             self._comm_stream = torch.cuda.Stream(self.params[0].device, priority=-1) if self.params[0].is_cuda else None
@@ -175,7 +187,10 @@ class FusedAdamOneCycle:
                     A._set_stream(main)
             comm.wait_stream(side)                 # weight gradients are produced on the side stream
         base = self.flat_grad.data_ptr()
+        prev = self._work_of.pop(b, None)
         with torch.cuda.stream(comm):
+            if prev is not None:
+                prev.wait()                        # a dirty bucket is re-packed: its first collective must have left the slice
             for s in range(lo, hi, 128):
                 part = range(s, min(hi, s + 128))
                 arr = (PackJob * len(part))()
@@ -187,11 +202,20 @@ class FusedAdamOneCycle:
                     arr[k].dst = base + 4 * int(self.offsets[i])
                     arr[k].numel = self.params[i].numel()
                 check(native.lib().rd_pack_grads_list(arr, len(part), _stream()), "rd_pack_grads_list")
-            self._works.append(dist.all_reduce(self.flat_grad[e0:e1], op=dist.ReduceOp.SUM, group=self.process_group, async_op=True))
+            w = dist.all_reduce(self.flat_grad[e0:e1], op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+            self._works.append(w)
+            self._work_of[b] = w
 
     def zero_grad(self):
         for p in self.params:
             p.grad = None
+        if getattr(self, 'buckets', None) is not None and (self._works or any(self.buckets.seen)):
+            # a backward pass that was not followed by step() (it raised, or its step was abandoned): collectives in flight are
+            # drained and the bucket bookkeeping starts clean, instead of carrying half-counted buckets into the next pass
+            for w in self._works:
+                w.wait()
+            self._works, self._work_of = [], {}
+            self.buckets.reset()
 
     def _fill_table(self):
         # gradient tensors are new objects every step but, in steady state, the allocator hands back the same addresses: when a
@@ -248,7 +272,7 @@ class FusedAdamOneCycle:
             for w in self._works:
                 w.wait()                                   # the current stream waits for the collective
             torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._comm_stream)
-            self._works = []
+            self._works, self._work_of = [], {}
             self.buckets.reset()
             return self.flat_grad, 1.0 / dist.get_world_size(self.process_group)
         if table is None:
@@ -257,30 +281,39 @@ class FusedAdamOneCycle:
         dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.process_group)
         return self.flat_grad, 1.0 / dist.get_world_size(self.process_group)
 
+    def _presence(self, table):
+        """Flat-buffer mode: the group-wide "has a gradient" mask of this step (rd_grad_presence + one MAX all-reduce of ~500 floats).
+        A parameter without a gradient on THIS rank only (a branch its batch did not use) then takes part like on the other ranks,
+        with the averaged gradient from the flat buffer -- same norm, same clip coefficient, same Adam step count everywhere."""
+        import torch.distributed as dist
+        check(native.lib().rd_grad_presence(_p(table), len(self.params), _p(self.present), _stream()), "rd_grad_presence")
+        dist.all_reduce(self.present, op=dist.ReduceOp.MAX, group=self.process_group)
+        return self.present
+
     def step(self, inv_loss_scale=None, overflow_count=None):
         """clip_grad_norm_(grad_clip) + OptimWrapper.step(); returns the device tensor [total_norm, clip_coef].
         inv_loss_scale: device scalar 1 / S when the loss was multiplied by S before backward (AmpScaler): norm and update use g / S
         and a non-finite norm skips the whole update on the device, as GradScaler.unscale_ / step do (train_utils.py:60-64);
-        overflow_count: device int32 counting the skipped steps (they are not Adam steps: bias correction uses step - overflows)."""
+        such a step is counted in self.overflows (they are not Adam steps: bias correction uses step - overflows).
+        overflow_count: accepted for callers of the round-2 signature; the optimizer's own counter is what is used."""
         table = self._fill_table()
         L = native.lib()
         flat, scale = self.allreduce_gradients(table)
+        present = self._presence(table) if flat is not None else None
         clip = None
         amp = inv_loss_scale is not None
+        overflow_count = self.overflows if (amp or self._amp_used) else None
+        self._amp_used = self._amp_used or amp
         if amp or (self.grad_clip is not None and self.grad_clip > 0):
             max_norm = float(self.grad_clip) if (self.grad_clip is not None and self.grad_clip > 0) else 0.0
             check(L.rd_grad_norm(_p(table), _p(self.chunks_dev), self.n_chunks, max_norm, _p(self.norm_out),
-                                 _p(self.ws), self.ws.numel() * 4, _p(flat), scale, _p(inv_loss_scale), _p(overflow_count), _stream()),
-                  "rd_grad_norm")
+                                 _p(self.ws), self.ws.numel() * 4, _p(flat), scale, _p(inv_loss_scale), _p(overflow_count if amp else None),
+                                 _p(present), _stream()), "rd_grad_norm")
             clip = self.norm_out
         self.step_count += 1
         check(L.rd_adam_step(_p(table), _p(self.chunks_dev), self.n_chunks, float(self.lr), float(self.mom), float(self.beta2),
                              float(self.eps), float(self.wd), self.step_count, _p(self.skipped_dev), _p(clip), _p(flat), scale,
-                             _p(inv_loss_scale), int(amp), _p(overflow_count), _stream()), "rd_adam_step")
-        absent = [i for i, p in enumerate(self.params) if p.grad is None]
-        if absent:                             # they sat this step out: their own Adam step count stays behind from now on
-            self.skipped[absent] += 1
-            self.skipped_dev = torch.from_numpy(self.skipped.copy()).to(self.params[0].device)
+                             _p(inv_loss_scale), int(amp), _p(overflow_count), _p(present), _stream()), "rd_adam_step")
         A.bump_weights_epoch()                 # parameters changed through raw pointers: invalidate cached weight layouts
         return self.norm_out
 
@@ -291,8 +324,10 @@ class FusedAdamOneCycle:
         leaves, split_bn_bias fastai_optim.py:16-28), parameters that never had a gradient carry no state."""
         state, off = {}, self.offsets
         order = [i for g in self.ref_groups for i in g]
+        skipped = self.skipped
+        overflows = int(self.overflows.item()) if self._amp_used else 0          # steps GradScaler skipped are nobody's Adam step
         for idx, i in enumerate(order):
-            own = self.step_count - int(self.skipped[i])
+            own = self.step_count - int(skipped[i]) - overflows
             if own <= 0:
                 continue
             p = self.params[i]
@@ -325,8 +360,8 @@ class FusedAdamOneCycle:
                 self.exp_avg[self.offsets[i]:self.offsets[i + 1]].copy_(st["exp_avg"].reshape(-1))
                 self.exp_avg_sq[self.offsets[i]:self.offsets[i + 1]].copy_(st["exp_avg_sq"].reshape(-1))
             self.step_count = int(steps.max()) if len(steps) else 0
-            self.skipped = (self.step_count - steps).astype(np.int32)
-            self.skipped_dev = torch.from_numpy(self.skipped.copy()).to(self.params[0].device) if self.skipped.any() else None
+            self.skipped_dev.copy_(torch.from_numpy((self.step_count - steps).astype(np.int32)))
+            self.overflows.zero_()             # the stored `step`s are free of overflow-skipped steps: counting restarts consistently
             g0 = sd["param_groups"][0]
             self.lr, self.mom = float(g0["lr"]), float(g0["betas"][0])
             return
@@ -336,8 +371,8 @@ class FusedAdamOneCycle:
         self.step_count = int(sd["step"])
         self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.lr, self.mom = sd["lr"], sd["mom"]
-        self.skipped[:] = 0
-        self.skipped_dev = None
+        self.skipped_dev.zero_()
+        self.overflows.zero_()
 
 
 def reference_param_groups(model):
@@ -399,7 +434,6 @@ class AmpScaler:
         self._scale = torch.full((), float(init_scale), dtype=torch.float32, device=device)
         self._inv = torch.full((1,), 1.0 / float(init_scale), dtype=torch.float32, device=device)
         self._tracker = torch.zeros((), dtype=torch.int32, device=device)
-        self._overflows = torch.zeros(1, dtype=torch.int32, device=device)
 
     def get_scale(self):
         return float(self._scale) if self.enabled else 1.0
@@ -411,7 +445,7 @@ class AmpScaler:
         """unscale_ + clip_grad_norm_ + optimizer.step(): one pass over the gradients; returns [norm of g / S, clip coefficient]."""
         if not self.enabled:
             return optimizer.step()
-        self._norm = optimizer.step(inv_loss_scale=self._inv, overflow_count=self._overflows)
+        self._norm = optimizer.step(inv_loss_scale=self._inv)          # overflow-skipped steps are counted by the optimizer (state_dict)
         return self._norm
 
     def update(self):

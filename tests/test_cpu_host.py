@@ -16,12 +16,12 @@ def test_library_exports_every_header_symbol():
     for s in syms:
         assert hasattr(L, s), s
     assert set(syms) == set(native.SIGNATURES)
-    assert L.rd_abi_version() == 2
+    assert L.rd_abi_version() == 3
     assert L.rd_rankgrid_bytes(32 * 1024) == (2 * 1024 + 1 + 1) * 4
     C = native.ctypes_lib()          # the same entry points through ctypes (what a reference maintainer's stub would use)
     for s in syms:
         assert hasattr(C, s), s
-    assert C.rd_abi_version() == 2 and C.rd_rankgrid_bytes(32 * 1024) == L.rd_rankgrid_bytes(32 * 1024)
+    assert C.rd_abi_version() == 3 and C.rd_rankgrid_bytes(32 * 1024) == L.rd_rankgrid_bytes(32 * 1024)
     with pytest.raises(TypeError):
         L.rd_rankgrid_bytes()          # the generated callers check their argument count
 

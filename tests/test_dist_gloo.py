@@ -100,6 +100,8 @@ def _bucket_worker(rank, world, port, q):
     works, order = [], []
 
     def launch(b):
+        for w in works:                                                # (a re-launched dirty bucket re-packs a slice a collective may still own)
+            w.wait()
         lo, hi = buckets.ranges[b]
         for i in range(lo, hi):
             g = params[i].grad
@@ -128,6 +130,28 @@ def _bucket_worker(rank, world, port, q):
             dist.all_reduce(g)
             ref.append(g)
         ok = ok and torch.equal(flat, torch.cat(ref)) and len(in_backward) >= 2 and in_backward[0] == 0
+    # gradient accumulation: TWO backward passes before the exchange is finished.  The second pass changes gradients whose buckets
+    # were already sent: they must be marked dirty and sent again with the accumulated values (never silently dropped)
+    for p in params:
+        p.grad = None
+    works.clear(); order.clear()
+    for k in range(2):
+        x = torch.randn(5, 40, generator=torch.Generator().manual_seed(100 + 10 * rank + k))
+        net(x).square().sum().backward()
+    first_pass = list(order)
+    assert buckets.dirty == set(first_pass) and len(first_pass) >= 2
+    for b in buckets.open_buckets():
+        launch(b)
+    for w in works:
+        w.wait()
+    assert sorted(order[len(first_pass):]) == list(range(len(buckets.ranges))) and not buckets.dirty
+    buckets.reset()
+    ref = []
+    for p in params:
+        g = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().clone().reshape(-1)
+        dist.all_reduce(g)
+        ref.append(g)
+    ok = ok and torch.equal(flat, torch.cat(ref))
     q.put((rank, ok, float(flat.abs().sum())))
     dist.destroy_process_group()
 

@@ -726,6 +726,40 @@ def test_halo_conv3x3_bf16x3(B, H, W, Cin, Cout):
         K.set_conv_math("f32")
 
 
+@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+def test_shared_weight_and_hooked_weight_gradients_with_deferred_layout(math):
+    """The deferred weight-gradient re-layout hands autograd an EMPTY tensor that is filled when the backward pass ends.  A Conv2d
+    weight used TWICE in one graph (autograd sums the two gradients before AccumulateGrad) and a weight with a tensor hook (reads
+    the gradient mid-pass) must not go through it: both against torch conv2d on the CPU."""
+    from radardistill_amd import autograd as A, kernels as K
+    g = np.random.default_rng(11)
+    B, H, W, C = 2, 12, 16, 64
+    x = torch.from_numpy(g.normal(size=(B, C, H, W)).astype(np.float32))
+    w = torch.from_numpy((g.normal(size=(C, C, 3, 3)) / np.sqrt(9 * C)).astype(np.float32))
+    w2 = torch.from_numpy((g.normal(size=(C, C, 3, 3)) / np.sqrt(9 * C)).astype(np.float32))
+    wr, w2r = w.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+    seen = []
+    w2r.register_hook(lambda gr: (seen.append(gr.detach().clone()), gr * 2.0)[1])
+    yr = F.conv2d(F.conv2d(F.conv2d(x, wr, None, 1, 1), w2r, None, 1, 1), wr, None, 1, 1)
+    yr.square().sum().backward()
+    K.set_conv_math(math)
+    try:
+        spec = A.dense_conv_spec(B, H, W, 3, 3, 1, 1)
+        rows = x.permute(0, 2, 3, 1).reshape(-1, C).contiguous().to(DEV)
+        wd, w2d = torch.nn.Parameter(w.to(DEV)), torch.nn.Parameter(w2.to(DEV))
+        got = []
+        w2d.register_hook(lambda gr: (got.append(gr.detach().clone()), gr * 2.0)[1])
+        A.begin_step(torch.device(DEV))
+        y = A.conv(A.conv(A.conv(rows, wd, None, spec, C), w2d, None, spec, C), wd, None, spec, C)
+        y.square().sum().backward()
+        torch.cuda.synchronize()
+        close(wd.grad, wr.grad, rtol=1e-3, atol=1e-3 * float(wr.grad.abs().max()), what="weight used twice")
+        close(got[0], seen[0], rtol=1e-3, atol=1e-3 * float(seen[0].abs().max()), what="gradient seen by the tensor hook")
+        close(w2d.grad, w2r.grad, rtol=1e-3, atol=1e-3 * float(w2r.grad.abs().max()), what="hooked weight")
+    finally:
+        K.set_conv_math("f32")
+
+
 # ------------------------------------------------------------------------------------------ inference post-processing (8(f) rank 2)
 def _clustered_boxes(n, seed):
     g = np.random.default_rng(seed)
@@ -794,6 +828,56 @@ def test_center_head_eval_decode_golden(golden_dir):
         # and the order itself is descending in score within each head's block, up to that fp noise
         sc = fd["pred_scores"].cpu().numpy(); lab = fd["pred_labels"].cpu().numpy()
         assert np.all(np.diff(sc)[np.diff(np.searchsorted([1, 2, 4, 6, 7, 9, 11], lab, side="right")) == 0] <= 1e-5)
+
+
+def test_config0_radar_only_graph_on_the_hip_path_vs_oracle():
+    """BASELINE configs[0]: the radar-only graph radar_distill_val.yaml builds (tools/cfgs/radar_distill/radar_distill_val.yaml:67 --
+    Radar_DynamicPillarVFESimple2D_Test -> Radar_PillarRes18BackBone8x -> Radar_Distill -> Radar_CenterHead, chained by
+    detectors/pillarnet.py:28-46), 1 000 radar points, 128 x 128 BEV, B = 1, eval mode: every map of the six task heads' pred dicts
+    from the HIP chain against oracle.pillarnet.forward_radar_only at 1e-3, in both arithmetic modes; the decoded boxes come out of
+    the same call.  The module list is derived from the bench yaml exactly as the reference's val yaml differs from its train yaml:
+    the teacher keys and DISTILL / FREEZE_PIPELINE removed, the test-time radar VFE that reads `points`."""
+    import os
+    from radardistill_amd import kernels as K
+    from radardistill_amd.data import SyntheticDistillDataset
+    from radardistill_amd.pcdet.config import AttrDict, cfg_from_yaml_file
+    from radardistill_amd.pcdet.models import build_network, load_data_to_gpu
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    c = cfg_from_yaml_file(os.path.join(root, "tools/cfgs/radar_distill/bench_512.yaml"), AttrDict())
+    for k in ("VFE", "BACKBONE_3D", "BACKBONE_2D", "DENSE_HEAD", "FREEZE_PIPELINE", "DISTILL"):
+        c.MODEL.pop(k, None)
+    c.MODEL.RADAR_VFE.NAME = "Radar_DynamicPillarVFESimple2D_Test"
+    grid = 128
+    pc_range, voxel, gs = bench_geometry(grid)
+    c.DATA_CONFIG.POINT_CLOUD_RANGE = pc_range
+    c.MODEL.RADAR_BACKBONE_2D.POINT_CLOUD_RANGE = pc_range
+    torch.manual_seed(0)
+    model = build_network(model_cfg=c.MODEL, num_class=len(c.CLASS_NAMES), dataset=SyntheticDistillDataset.from_cfg(c))
+    assert [type(m).__name__ for m in model.module_list] == ["Radar_DynamicPillarVFESimple2D_Test", "Radar_PillarRes18BackBone8x", "Radar_Distill",
+                                                              "Radar_CenterHead"]
+    sd = model.state_dict(); seeded_fill_(sd, seed=31); model.load_state_dict(sd)
+    b = make_batch(batch_size=1, n_lidar=16, n_radar=1000, n_boxes=4, grid=grid, seed=0)
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        want = opn.forward_radar_only(state, torch.from_numpy(b["radar_points"]), 1, pc_range, voxel, gs)
+    assert len(want) == 6
+    model = model.to(DEV).eval()
+    for math in ("f32", "bf16x3"):
+        K.set_conv_math(math)
+        try:
+            bd = {"points": b["radar_points"].copy(), "gt_boxes": b["gt_boxes"].copy(), "batch_size": 1}      # the radar-only test set hands its sweep over as `points`
+            load_data_to_gpu(bd)
+            with torch.no_grad():
+                final, recall = model(bd)
+            got = model.radar_dense_head.forward_ret_dict["pred_dicts"]
+            assert len(got) == 6 and len(final) == 1 and final[0]["pred_boxes"].shape[1] == 9
+            for h, (gd, wd) in enumerate(zip(got, want)):
+                assert set(gd) == set(wd) == {"center", "center_z", "dim", "rot", "vel", "iou", "hm"}
+                for name in wd:
+                    assert tuple(gd[name].shape) == tuple(wd[name].shape) == (1, wd[name].shape[1], grid // 8, grid // 8)
+                    close(gd[name], wd[name], rtol=1e-3, atol=1e-3 * float(wd[name].abs().max()), what=f"{math} head {h} {name}")
+        finally:
+            K.set_conv_math("f32")
 
 
 def test_pillarnet_eval_forward_and_recall():

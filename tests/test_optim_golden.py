@@ -226,3 +226,29 @@ def test_amp_loss_scaling_matches_torch_gradscaler():
         for p, r in zip(ps, rs):
             np.testing.assert_allclose(p.detach().cpu().numpy(), r.detach().cpu().numpy(), rtol=2e-5, atol=1e-6, err_msg=f"step {it}")
     assert mine.get_scale() == theirs.get_scale()
+    # checkpoint / resume through an overflow-skipped step: the stored Adam `step` of every parameter is free of the skipped step (5, as
+    # in torch's own state), and an optimizer restored from it continues exactly like torch's (bias correction would shift otherwise)
+    sd = opt.state_dict()
+    for idx, r in enumerate(rs):
+        assert sd["state"][idx]["step"] == int(ref.state[r]["step"]) == 5
+    ps2 = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt2 = FusedAdamOneCycle(ps2, wd=0.01, grad_clip=10.0)
+    opt2.load_state_dict(sd)
+    grads = [torch.randn(s, generator=g) * 0.5 for s in shapes]
+    for o, pp in ((opt, ps), (opt2, ps2)):
+        for p, gg in zip(pp, grads):
+            p.grad = gg.to(dev).clone()
+        o.lr, o.mom = lr, mom
+        o.step()
+    with torch.no_grad():
+        for r, gg in zip(rs, grads):
+            r.grad = gg.to(dev).clone()
+        torch.nn.utils.clip_grad_norm_(rs, 10.0)
+        before = [r.detach().clone() for r in rs]
+    ref.step()
+    with torch.no_grad():
+        for r, b in zip(rs, before):
+            r.copy_(b * (1 - wd * lr) + (r - b))
+    for p, p2, r in zip(ps, ps2, rs):
+        np.testing.assert_allclose(p2.detach().cpu().numpy(), r.detach().cpu().numpy(), rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(p.detach().cpu().numpy(), r.detach().cpu().numpy(), rtol=2e-5, atol=1e-6)

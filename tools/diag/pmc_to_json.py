@@ -45,7 +45,9 @@ def main():
     note = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python3 bench.py --steps 3 --warmup 1 "
             "--no-cpu-baseline --other-math-steps 0`, averaged per dispatch. gfx950 correction per MI355X_MICROARCH.md section HBM: FETCH_SIZE "
             "reports 1/2 of wide coalesced reads -> doubled; WRITE_SIZE exact. Infinity-Cache hits are included in FETCH_SIZE (fabric-side counter).")
-    json.dump({"note": note, "kernels": kernels}, open(out, "w"), indent=1)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+    from radardistill_amd import native
+    json.dump({"note": note, "csrc_sha": native.csrc_sha(), "kernels": kernels}, open(out, "w"), indent=1)
     for k, v in list(kernels.items())[:12]:
         print(v["dispatches"], v["hbm_bytes_per_launch_corrected"], k[:100])
 
