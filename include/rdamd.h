@@ -177,6 +177,12 @@ int rd_get_conv_math(void);
  * rd_conv_fwd_split / rd_conv_wgrad_split are rd_conv_fwd / rd_conv_wgrad with a flag per operand saying which format it is in
  * (bf16x3 mode only; an input sampled by a deformable index must stay fp32). */
 int rd_split_bf16(const float *x, int64_t n, void *out, void *stream);
+/* kind | RD_LAYOUT_FRAG: FRAGMENT-MAJOR split format for weights -- the destination [A][taps][B] (B = the consuming GEMM's K axis) is
+ * stored in blocks of 32 (A) x 16 (B) of one tap, each block as the two 1-KiB operand images of v_mfma_f32_32x32x16_bf16 (hi parts,
+ * then lo parts; lane 32 * kh + r: A-row r, B-elements 8 kh .. +7), so a wavefront loads a B fragment with one coalesced 16-byte-per-
+ * lane read from L2 and the kernel needs no LDS staging for the weights.  A % 32 == 0, B % 16 == 0; same size as the fp32 tensor.
+ * Consumed by rd_conv_fwd_split with w_is_split = 2 (dense stride-1 3x3 convolutions and 1-tap GEMMs in bf16x3 mode). */
+#define RD_LAYOUT_FRAG 16
 int rd_weight_layout_split(const float *src, void *dst, int Cout, int Cin, int taps, int kind, int flip, void *stream);
 /* The same conversion for MANY weights in one launch (all trainable conv weights once per optimizer step).  jobs_dev: device array of
  * jobs (kinds as rd_weight_layout_split, no tap flip); chunk c (one 256-thread workgroup) converts work item chunk_group[c] of job

@@ -118,6 +118,7 @@ def begin_step(device):
     if device.type == "cuda":
         _OPERANDS.refresh_all(device)
     _BN_TOUCHED.clear()
+    _PARAM_USES.clear()
     _WGRAD_JOIN_QUEUED[0] = False
     _DEFER_QUEUED[0] = False
     _DEFERRED_LAYOUT.clear()
@@ -280,11 +281,12 @@ class _OperandCache:
 _OPERANDS = _OperandCache()
 
 
-def operand_weight_split(param, Cout, Cin, taps, param_kind, dgrad=False):
+def operand_weight_split(param, Cout, Cin, taps, param_kind, dgrad=False, frag=False):
     """Parameter (layout `param_kind`: 0 [Cout][taps][Cin], 1 torch Conv2d, 3 torch ConvTranspose2d) -> split-format GEMM operand:
     [Cout][taps][Cin] for the forward, [Cin][taps][Cout] for the data gradient.  Leaf parameters go through the persistent operand
-    cache (one refresh launch per step for all of them); a per-step tensor (the concatenated CenterHead branches) is converted here."""
-    kind = _DGRAD_KIND[param_kind] if dgrad else param_kind
+    cache (one refresh launch per step for all of them); a per-step tensor (the concatenated CenterHead branches) is converted here.
+    frag: fragment-major split format (kernels.wants_frag_weights says when the launch takes it)."""
+    kind = (_DGRAD_KIND[param_kind] if dgrad else param_kind) | (K.LAYOUT_FRAG if frag else 0)
     if not param.is_leaf:
         src = param.detach()
         return K.weight_layout_split(src if src.is_contiguous() else src.contiguous(), Cout, Cin, taps, kind, False)
@@ -354,6 +356,19 @@ def _set_stream(s):
         torch.cuda.set_stream(s)
 
 
+# How often each parameter was consumed by a Function of THIS step's graph (id -> count; reset by begin_step, counted in the
+# forwards below).  A parameter used more than once receives the SUM of its gradients: the autograd engine adds them on the main
+# stream the moment the second one exists -- long before the join -- so neither may come from the side stream or be a deferred
+# (still empty) tensor.
+_PARAM_USES = {}
+
+
+def note_param_use(*params):
+    for p in params:
+        if p is not None and p.requires_grad:
+            _PARAM_USES[id(p)] = _PARAM_USES.get(id(p), 0) + 1
+
+
 def _side_ok(param):
     """A gradient produced on the side stream must not be READ on the main stream before the join at the end of the backward pass.
     Autograd only aliases it (AccumulateGrad steals a fresh, layout-conforming tensor; CatBackward hands out views) when the
@@ -361,6 +376,8 @@ def _side_ok(param):
     the main stream.  A non-leaf weight (the concatenated CenterHead branches) names its leaves in `_rd_leaves`."""
     if param is None:
         return True
+    if _PARAM_USES.get(id(param), 0) > 1:
+        return False
     leaves = getattr(param, "_rd_leaves", None)
     if leaves is not None:
         return (not param.is_leaf or param.grad is None) and all(p.grad is None for p in leaves)
@@ -581,11 +598,13 @@ class _ConvFn(torch.autograd.Function):
     def forward_impl(ctx, x, weight, bias, spec, Cout, stats):
         """The convolution launch + what its backward needs on `ctx` (shared with _ConvBNActFn); the caller saves x and weight."""
         Cin = x.shape[1]
+        note_param_use(weight, bias)
         ctx.xs = None
         if _b3_wsplit(Cin, Cout):
             wk = None
-            out = K.conv_fwd(x, operand_weight_split(weight, Cout, Cin, spec.taps, spec.param_kind), spec.taps, bias, spec.out_rows, Cout,
-                             spec.fwd_ix, stats=stats, nbr_keepalive=spec.fwd_nbr, w_split=True)
+            frag = K.wants_frag_weights(spec.fwd_ix, spec.in_rows, spec.out_rows, Cin, Cout, spec.taps)
+            out = K.conv_fwd(x, operand_weight_split(weight, Cout, Cin, spec.taps, spec.param_kind, frag=frag), spec.taps, bias, spec.out_rows, Cout,
+                             spec.fwd_ix, stats=stats, nbr_keepalive=spec.fwd_nbr, w_split=2 if frag else True)
             ctx.spec, ctx.Cout, ctx.Cin = spec, Cout, Cin
             ctx.has_bias = bias is not None
             ctx.bias_ref = bias
@@ -626,8 +645,9 @@ class _ConvFn(torch.autograd.Function):
             if use_ws:
                 # bf16x3: [Cin][taps][Cout] split-format operand straight from the parameter (unchanged since the forward: the
                 # optimizer runs after backward)
-                wds = operand_weight_split(weight, Cout, Cin, spec.taps, spec.param_kind, dgrad=True)
-                gx = K.conv_fwd(grad_out, wds, spec.taps, None, spec.in_rows, Cin, spec.bwd_ix, nbr_keepalive=spec.bwd_nbr, w_split=True)
+                frag = K.wants_frag_weights(spec.bwd_ix, spec.out_rows, spec.in_rows, Cout, Cin, spec.taps)
+                wds = operand_weight_split(weight, Cout, Cin, spec.taps, spec.param_kind, dgrad=True, frag=frag)
+                gx = K.conv_fwd(grad_out, wds, spec.taps, None, spec.in_rows, Cin, spec.bwd_ix, nbr_keepalive=spec.bwd_nbr, w_split=2 if frag else True)
             elif Cout % 32 == 0 and K.get_conv_math() == "f32":
                 gx = K.conv_dgrad(grad_out, wk, spec.taps, spec.in_rows, Cin, spec.bwd_ix, nbr_keepalive=spec.bwd_nbr)   # forward weights, read transposed
             elif Cout % 32 == 0 and _b3_presplit(Cout, Cin, spec.bwd_ix.mode):
@@ -695,8 +715,10 @@ def conv_inference(x, weight, bias, spec, Cout, scale=None, shift=None, residual
     """Frozen path (teacher): conv + folded eval-mode BatchNorm + residual + ReLU in ONE kernel, no graph."""
     Cin = x.shape[1]
     if _b3_wsplit(Cin, Cout):
-        return K.conv_fwd(x, operand_weight_split(weight, Cout, Cin, spec.taps, spec.param_kind), spec.taps, bias, spec.out_rows, Cout,
-                          spec.fwd_ix, scale=scale, shift=shift, residual=residual, relu=relu, nbr_keepalive=spec.fwd_nbr, w_split=True)
+        frag = K.wants_frag_weights(spec.fwd_ix, spec.in_rows, spec.out_rows, Cin, Cout, spec.taps)
+        return K.conv_fwd(x, operand_weight_split(weight, Cout, Cin, spec.taps, spec.param_kind, frag=frag), spec.taps, bias, spec.out_rows, Cout,
+                          spec.fwd_ix, scale=scale, shift=shift, residual=residual, relu=relu, nbr_keepalive=spec.fwd_nbr,
+                          w_split=2 if frag else True)
     wk = kernel_weight(weight, Cout, Cin, spec.taps, spec.param_kind)
     if _b3_presplit(Cin, Cout, spec.fwd_ix.mode):
         return K.conv_fwd(split_activation(x), kernel_weight_split(weight, wk, Cout, Cin, spec.taps), spec.taps, bias, spec.out_rows, Cout,
@@ -944,6 +966,7 @@ class _DWConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_rows, weight, bias, B, H, W):
         C, K = weight.shape[0], weight.shape[-1]
+        note_param_use(weight, bias)
         w_tc = weight.detach().reshape(C, K * K).t().contiguous()
         out = K_.dwconv_fwd(x_rows, w_tc, bias.detach() if bias is not None else None, B, H, W, K)
         ctx.geom = (B, H, W, K)
@@ -980,6 +1003,7 @@ class _NConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, weight, bias, B, H, W, tab):
+        note_param_use(weight, bias)
         out = K.nconv_fwd(y, weight.detach().contiguous(), bias.detach().contiguous() if bias is not None else None, B, H, W, tab)
         ctx.geom, ctx.tab, ctx.has_bias = (B, H, W), tab, bias is not None
         ctx.bias_ref = bias
@@ -1011,6 +1035,7 @@ class _BNNConvFn(torch.autograd.Function):
     def forward(ctx, raw, gamma, beta, running_mean, running_var, eps, momentum, stats, weight, bias, B, H, W, tab):
         if stats is None:
             stats = K.bn_stats(raw)
+        note_param_use(weight, bias)
         y, side = K.bn_train_fwd(raw, stats, gamma, beta, eps, momentum, running_mean, running_var, None, 1)
         out = K.nconv_fwd(y, weight.detach().contiguous(), bias.detach().contiguous() if bias is not None else None, B, H, W, tab)
         ctx.geom, ctx.tab, ctx.bias_ref = (B, H, W), tab, bias

@@ -262,6 +262,8 @@ extern "C" int rd_get_conv_math(void) { return g_conv_math; }
 static int conv_fwd_impl(const float *in, int in_rows, int Cin, const float *weight_k, int taps, const float *bias, float *out,
                          int out_rows, int Cout, const rd_conv_index *idx, const float *scale, const float *shift,
                          const float *residual, int relu, float *stats, int in_split, int w_split, void *stream);
+bool conv_d3f_applies(const ConvArgs &a);                      // conv_d3f.hip
+int launch_conv_d3f_b3(const ConvArgs &a, hipStream_t st);
 
 extern "C" int rd_conv_fwd(const float *in, int in_rows, int Cin, const float *weight_k, int taps, const float *bias, float *out,
                            int out_rows, int Cout, const rd_conv_index *idx, const float *scale, const float *shift,
@@ -277,7 +279,7 @@ extern "C" int rd_conv_fwd_split(const void *in, int in_is_split, int in_rows, i
     RD_REQUIRE(g_conv_math == 1 && Cout > 32, "rd_conv_fwd_split: needs bf16x3 mode (rd_set_conv_math(1)) and Cout > 32");
     RD_REQUIRE(!(idx && idx->mode == 3 && in_is_split), "rd_conv_fwd_split: a deformable conv blends fp32 input rows (pass the input unsplit)");
     return conv_fwd_impl(reinterpret_cast<const float *>(in), in_rows, Cin, reinterpret_cast<const float *>(weight_k), taps, bias, out, out_rows,
-                         Cout, idx, scale, shift, residual, relu, stats, in_is_split ? 1 : 0, w_is_split ? 1 : 0, stream);
+                         Cout, idx, scale, shift, residual, relu, stats, in_is_split ? 1 : 0, w_is_split == 2 ? 2 : (w_is_split ? 1 : 0), stream);
 }
 
 static int conv_fwd_impl(const float *in, int in_rows, int Cin, const float *weight_k, int taps, const float *bias, float *out,
@@ -302,6 +304,13 @@ static int conv_fwd_impl(const float *in, int in_rows, int Cin, const float *wei
     a.w_split = w_split;
     hipStream_t st = S(stream);
     dim3 block(256);
+    if (w_split == 2) {          // weights in fragment-major split format (RD_LAYOUT_FRAG): only the kernels that read fragments from L2
+        RD_REQUIRE(g_conv_math == 1 && conv_d3f_applies(a),
+                   "rd_conv_fwd_split: fragment-major weights (w_is_split = 2) need bf16x3 mode and a dense stride-1 3x3 convolution with "
+                   "Cin %% 32 == 0, Cout %% 32 == 0, fp32 activations (Cin %d, Cout %d, taps %d, mode %d)", Cin, Cout, taps, idx->mode);
+        launch_conv_d3f_b3(a, st);
+        return check_launch("rd_conv_fwd(bf16x3, fragment-major weights)");
+    }
     if (g_conv_math == 1 && Cout > 32) {
         launch_conv_b3(a, idx->mode, st);
         return check_launch("rd_conv_fwd(bf16x3)");
@@ -712,8 +721,51 @@ __global__ void k_weight_layout_split(const float *src, uint2 *dst_hi_lo, int Co
     dst_hi_lo[2 * g + 1] = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
 }
 
+// FRAGMENT-MAJOR split format (kind | RD_LAYOUT_FRAG): the destination [A][taps][B] (B = the GEMM's K axis) is cut into blocks of
+// 32 (A) x 16 (B) of one tap, and a block is stored as the two 1-KiB images a wavefront feeds to v_mfma_f32_32x32x16_bf16 as its B
+// operand -- first the hi parts, then the lo parts, each as 64 x 16 bytes: lane l = 32 * kh + r holds A-row r, B-elements 8 kh .. 8 kh + 7.
+// A wave therefore fetches an operand fragment with ONE fully coalesced 16-byte-per-lane load straight from L2, no LDS staging:
+//   unit16(a, t, b, part) = (((a >> 5) * taps + t) * (B >> 4) + (b >> 4)) * 128 + part * 64 + ((b >> 3) & 1) * 32 + (a & 31)
+// Same size as the fp32 tensor.  A % 32 == 0, B % 16 == 0.
+__device__ __forceinline__ int64_t frag_unit(int a, int t, int b, int taps, int B) {
+    return ((((int64_t)(a >> 5) * taps + t) * (B >> 4) + (b >> 4)) << 7) + (((b >> 3) & 1) << 5) + (a & 31);
+}
+
+__global__ void k_weight_layout_frag(const float *src, uint4 *dst, int Cout, int Cin, int taps, int kind, int flip) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // one thread per 8 consecutive destination elements
+    if (g * 8 >= (int64_t)Cout * Cin * taps) return;
+    const bool b_is_cin = kind == 0 || kind == 1 || kind == 3;
+    const int A = b_is_cin ? Cout : Cin, B = b_is_cin ? Cin : Cout;
+    const int64_t i0 = g * 8;
+    const int b = (int)(i0 % B), t = (int)((i0 / B) % taps), a = (int)(i0 / ((int64_t)B * taps));
+    unsigned short hi[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float v = src[layout_src(i0 + e, Cout, Cin, taps, kind, flip)];
+        const __bf16 h = (__bf16)v;
+        const __bf16 l = (__bf16)(v - (float)h);
+        hi[e] = __builtin_bit_cast(unsigned short, h);
+        lo[e] = __builtin_bit_cast(unsigned short, l);
+    }
+    const int64_t u = frag_unit(a, t, b, taps, B);
+    (void)A;
+    dst[u] = make_uint4(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16), hi[4] | ((unsigned)hi[5] << 16), hi[6] | ((unsigned)hi[7] << 16));
+    dst[u + 64] = make_uint4(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16), lo[4] | ((unsigned)lo[5] << 16), lo[6] | ((unsigned)lo[7] << 16));
+}
+
 // destination in split format: kinds whose destination's fastest axis has a multiple-of-4 extent (the K axis of the consuming GEMM)
 extern "C" int rd_weight_layout_split(const float *src, void *dst, int Cout, int Cin, int taps, int kind, int flip, void *stream) {
+    if (kind & RD_LAYOUT_FRAG) {
+        const int k = kind & ~RD_LAYOUT_FRAG;
+        RD_REQUIRE((k >= 0 && k <= 3) || k == 7 || k == 8, "rd_weight_layout_split: kinds 0..3, 7, 8 (operand layouts) only, got %d", k);
+        const bool b_is_cin = k == 0 || k == 1 || k == 3;
+        RD_REQUIRE((b_is_cin ? Cout : Cin) % 32 == 0 && (b_is_cin ? Cin : Cout) % 16 == 0,
+                   "rd_weight_layout_split: fragment-major needs the slow axis %% 32 == 0 and the fast (K) axis %% 16 == 0 (Cout %d, Cin %d, kind %d)", Cout, Cin, k);
+        const int64_t total = (int64_t)Cout * Cin * taps;
+        if (total <= 0) return RD_OK;
+        k_weight_layout_frag<<<cdiv(total / 8, 256), 256, 0, S(stream)>>>(src, reinterpret_cast<uint4 *>(dst), Cout, Cin, taps, k, flip);
+        return check_launch("rd_weight_layout_split(fragment-major)");
+    }
     RD_REQUIRE((kind >= 0 && kind <= 3) || kind == 7 || kind == 8, "rd_weight_layout_split: kinds 0..3, 7, 8 (operand layouts) only, got %d", kind);
     RD_REQUIRE((kind == 2 || kind >= 7 ? Cout : Cin) % 4 == 0, "rd_weight_layout_split: the destination's fastest axis must be a multiple of 4");
     int64_t total = (int64_t)Cout * Cin * taps;
@@ -745,7 +797,9 @@ __device__ __forceinline__ void layout_strides(int kind, int Cout, int Cin, int 
 __global__ __launch_bounds__(256) void k_weight_layout_split_multi(const rd_layout_job *__restrict__ jobs, const int *__restrict__ chunk_job,
                                                                    const int *__restrict__ chunk_group) {
     __shared__ __attribute__((aligned(16))) float tile[WL_TA * WL_TT * WL_LD];
-    const rd_layout_job j = jobs[chunk_job[blockIdx.x]];
+    rd_layout_job j = jobs[chunk_job[blockIdx.x]];
+    const bool frag = (j.kind & RD_LAYOUT_FRAG) != 0;          // fragment-major destination (see k_weight_layout_frag)
+    j.kind &= ~RD_LAYOUT_FRAG;
     int A, B;
     int64_t sa, st, sb;
     layout_strides(j.kind, j.Cout, j.Cin, j.taps, A, B, sa, st, sb);
@@ -778,6 +832,26 @@ __global__ __launch_bounds__(256) void k_weight_layout_split_multi(const rd_layo
         }
     }
     __syncthreads();
+    if (frag) {          // groups of 8 along b -> one 16-byte hi unit and one lo unit (consecutive a = consecutive units: 16 x 16 B runs)
+        uint4 *dstf = reinterpret_cast<uint4 *>(j.dst);
+        const int gb8 = tb / 8, n_g8 = ta * tt * gb8;
+        for (int g = threadIdx.x; g < n_g8; g += 256) {
+            const int a = g % ta, r = g / ta, b8 = r % gb8, t = r / gb8;
+            const float *v = &tile[(a * WL_TT + t) * WL_LD + 8 * b8];
+            unsigned short hi[8], lo[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const __bf16 h = (__bf16)v[e];
+                const __bf16 l = (__bf16)(v[e] - (float)h);
+                hi[e] = __builtin_bit_cast(unsigned short, h);
+                lo[e] = __builtin_bit_cast(unsigned short, l);
+            }
+            const int64_t u = frag_unit(a0 + a, t0 + t, b0 + 8 * b8, j.taps, B);
+            dstf[u] = make_uint4(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16), hi[4] | ((unsigned)hi[5] << 16), hi[6] | ((unsigned)hi[7] << 16));
+            dstf[u + 64] = make_uint4(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16), lo[4] | ((unsigned)lo[5] << 16), lo[6] | ((unsigned)lo[7] << 16));
+        }
+        return;
+    }
     // ---- write in destination order: groups of 4 along b
     uint2 *dst = reinterpret_cast<uint2 *>(j.dst);
     const int gb = tb / 4, n_g = ta * tt * gb;
@@ -800,6 +874,7 @@ __global__ __launch_bounds__(256) void k_weight_layout_split_multi(const rd_layo
 
 // number of work items (16 x 64 x <= 9 tiles) of one job: the host builds chunk_job / chunk_group from it
 extern "C" int rd_weight_layout_split_items(int Cout, int Cin, int taps, int kind) {
+    kind &= ~RD_LAYOUT_FRAG;
     const int A = (kind == 0 || kind == 1 || kind == 3) ? Cout : Cin, B = (kind == 0 || kind == 1 || kind == 3) ? Cin : Cout;
     return ((A + WL_TA - 1) / WL_TA) * ((B + WL_TB - 1) / WL_TB) * ((taps + WL_TT - 1) / WL_TT);
 }

@@ -261,11 +261,18 @@ def split_bf16(x):
     return out
 
 
-def weight_layout_split(src, Cout, Cin, taps, kind, flip=False, out=None):
-    """Like weight_layout (operand kinds 0..3, 7, 8) with the destination written in split format (into `out` if given)."""
+def weight_layout_split(src, Cout, Cin, taps, kind, flip=False, out=None, frag=False):
+    """Like weight_layout (operand kinds 0..3, 7, 8) with the destination written in split format (into `out` if given).
+    frag (or kind | LAYOUT_FRAG): fragment-major split format (include/rdamd.h, RD_LAYOUT_FRAG)."""
     _chk(src, f32, "weight")
+    if frag:
+        kind |= LAYOUT_FRAG
     if src.numel() != Cout * Cin * taps:
         raise RuntimeError("weight_layout_split: element count mismatch")
+    if kind & LAYOUT_FRAG:
+        a_, b_ = (Cout, Cin) if (kind & ~LAYOUT_FRAG) in (0, 1, 3) else (Cin, Cout)
+        if a_ % 32 or b_ % 16:
+            raise RuntimeError(f"weight_layout_split: fragment-major needs slow axis % 32 == 0 and K axis % 16 == 0, got {a_} x {b_}")
     if out is None:
         out = torch.empty(Cout * Cin * taps, dtype=f32, device=src.device)
     elif _chk(out, f32, "split destination").numel() != Cout * Cin * taps:
@@ -285,9 +292,31 @@ def weight_layout_split_multi(jobs_dev, chunk_job_dev, chunk_group_dev, n_chunks
           "rd_weight_layout_split_multi")
 
 
-def _kernel_tag(ix, in_rows, out_rows, Cin, Cout, taps, in_split, tile):
+D3F = os.environ.get("RD_D3F", "1") != "0"          # A/B switch: dense 3x3 convolutions on the fragment-major-weights kernel (conv_d3f.hip)
+LAYOUT_FRAG = 16                                     # RD_LAYOUT_FRAG of include/rdamd.h
+
+
+def wants_frag_weights(ix, in_rows, out_rows, Cin, Cout, taps):
+    """True when rd_conv_fwd_split should get this convolution's weights in FRAGMENT-MAJOR split format (w_split = 2): bf16x3 mode, dense
+    stride-1 3x3 geometry on same-size maps (forward: mode 1, data gradient: mode 2), Cin % 32 == 0, Cout % 32 == 0, and a map large
+    enough for 8 x 16-pixel tiles to give every CU a workgroup (smaller maps keep the LDS-staged kernel's 8 x 8 tiles).  Mirrors
+    conv_d3f_applies / launch_conv_d3f_b3 (conv_d3f.hip)."""
+    if not (D3F and get_conv_math() == "bf16x3" and ix.mode in (1, 2) and taps == 9 and ix.KH == 3 and ix.KW == 3 and ix.stride == 1 and ix.pad == 1
+            and ix.Hin == ix.Hout and ix.Win == ix.Wout and Cin % 32 == 0 and Cout % 32 == 0 and Cout >= 64 and in_rows == out_rows):
+        return False
+    hw = ix.Hout * ix.Wout
+    if hw <= 0 or out_rows % hw:
+        return False
+    big_rows = (out_rows // hw) * ((ix.Hout + 7) // 8) * ((ix.Wout + 15) // 16)
+    return big_rows * ((Cout + 63) // 64) >= 256
+
+
+def _kernel_tag(ix, in_rows, out_rows, Cin, Cout, taps, in_split, tile, w_split=0):
     """Which instantiation rd_conv_fwd launches (mirrors the dispatch in conv.hip / conv_b3.hip; used by bench.py's roofline only):
     128 / 64 = gathered implicit-GEMM tile, "d3_128" / "d3_16x64" / "d3_64" = halo-staged dense 3x3 kernel (bf16x3 mode; pre-split weights assumed for the middle one)."""
+    if w_split == 2:          # fragment-major weights: k_conv_d3f_b3 (launch_conv_d3f_b3)
+        big_rows = (out_rows // (ix.Hout * ix.Wout)) * ((ix.Hout + 7) // 8) * ((ix.Wout + 15) // 16)
+        return "d3f_128" if (Cout >= 128 and big_rows * ((Cout + 127) // 128) >= 384) else "d3f_64"
     if (get_conv_math() == "bf16x3" and ix.mode in (1, 2) and taps == 9 and ix.KH == 3 and ix.KW == 3 and ix.stride == 1 and ix.pad == 1
             and ix.Hin == ix.Hout and ix.Win == ix.Wout and Cin % 32 == 0 and not in_split and in_rows == out_rows
             and os.environ.get("RD_D3", "1") != "0"):
@@ -313,7 +342,8 @@ def _kernel_tag(ix, in_rows, out_rows, Cin, Cout, taps, in_split, tile):
 def conv_fwd(x, weight_k, taps, bias, out_rows, Cout, ix, scale=None, shift=None, residual=None, relu=False, stats=None, nbr_keepalive=None,
              in_split=False, w_split=False):
     """x (in_rows, Cin); weight_k (Cout, taps, Cin) kernel layout -> (out_rows, Cout).  in_split / w_split: that operand is already in
-    split format (bf16x3 mode)."""
+    split format (bf16x3 mode); w_split = 2: the weights are in FRAGMENT-MAJOR split format (weight_layout_split(..., frag=True);
+    only where wants_frag_weights() says so)."""
     _chk(x, f32, "conv input", 2)
     _chk(weight_k, f32, "conv weight")
     in_rows, Cin = x.shape
@@ -340,7 +370,7 @@ def conv_fwd(x, weight_k, taps, bias, out_rows, Cout, ix, scale=None, shift=None
         tile = 128 if ((out_rows + 127) // 128) * ((Cout + 127) // 128) >= 384 else 64
         if taps == 1 and get_conv_math() == "bf16x3" and os.environ.get("RD_GEMM_TILE64", "1") != "0":
             tile = 64          # 1-tap layers: 64x64 tiles whatever the size (launch_conv_b3)
-        tile = _kernel_tag(ix, in_rows, out_rows, Cin, Cout, taps, in_split, tile)
+        tile = _kernel_tag(ix, in_rows, out_rows, Cin, Cout, taps, in_split, tile, int(w_split))
         prof = PROFILE_TAGS is None or tile in PROFILE_TAGS
     if prof:
         e0 = timing_event(); e1 = timing_event()

@@ -38,6 +38,7 @@ class _DCNFn(torch.autograd.Function):
         samp_idx, samp_w = K.dcn_prep(om_rows, S, mask_base, S, sig, B, H, W, Ho, Wo, k, stride, pad)
         rows_o = B * Ho * Wo
         col = None
+        A.note_param_use(weight, bias)
         if DCN_COLUMNS and x_rows.is_cuda and Cin % 4 == 0:
             # column form: the sampled, modulated input rows are written once (rows x taps*Cin) and the convolution is a plain GEMM
             # over them; the backward's weight gradient re-uses the same columns (kept: 75 MB at the CMA shapes)

@@ -616,6 +616,15 @@ def test_operand_cache_multi_refresh_matches_single_conversions():
     params = [torch.nn.Parameter(torch.randn(*sh, generator=g).to(DEV)) for sh, _, _, _, _ in shapes]
     cache = A._OperandCache()
 
+    def frag_reference(dst_order):
+        """[A][taps][B] fp32 in destination order -> the fragment-major split image, built with torch ops (include/rdamd.h, RD_LAYOUT_FRAG):
+        per 32 (A) x 16 (B) block of a tap the hi then the lo operand image, each [k-half][row][8 elements]."""
+        A_, T_, B_ = dst_order.shape
+        hi = dst_order.bfloat16()
+        lo = (dst_order - hi.float()).bfloat16()
+        parts = [t.view(A_ // 32, 32, T_, B_ // 16, 2, 8).permute(0, 2, 3, 4, 1, 5) for t in (hi, lo)]
+        return torch.stack(parts, dim=3).contiguous().view(torch.int16).reshape(-1)
+
     def check_all():
         for p_, (_, pk, Cout, Cin, taps) in zip(params, shapes):
             for dgrad in (False, True):
@@ -623,6 +632,13 @@ def test_operand_cache_multi_refresh_matches_single_conversions():
                 got = cache.get(p_, Cout, Cin, taps, kind)
                 want = K.weight_layout_split(p_.detach().contiguous(), Cout, Cin, taps, kind, False)
                 assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (pk, dgrad)
+                if Cout % 32 == 0 and Cin % 32 == 0:          # fragment-major variant of the same operand
+                    gotf = cache.get(p_, Cout, Cin, taps, kind | K.LAYOUT_FRAG)
+                    wantf = K.weight_layout_split(p_.detach().contiguous(), Cout, Cin, taps, kind, False, frag=True)
+                    assert torch.equal(gotf.view(torch.int32), wantf.view(torch.int32)), (pk, dgrad, "frag")
+                    plain = K.weight_layout(p_.detach().contiguous(), Cout, Cin, taps, kind)          # destination order, fp32
+                    a_, b_ = (Cout, Cin) if not dgrad else (Cin, Cout)
+                    assert torch.equal(wantf.view(torch.int16).reshape(-1), frag_reference(plain.view(a_, taps, b_))), (pk, dgrad, "frag layout")
 
     check_all()                                              # entries created one by one
     with torch.no_grad():
@@ -689,6 +705,7 @@ def test_stream_overlaps_do_not_change_gradients():
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 21, 19, 64, 96),      # ragged map, 8x8 pixel tiles, Cout not a tile multiple
                                             (8, 64, 48, 64, 256),     # 8x16 pixel tiles (>= 384 workgroups)
+                                            (3, 24, 40, 96, 64),      # 64-column tile of the fragment-major kernel, 3 K chunks
                                             (1, 8, 16, 32, 33)])
 def test_halo_conv3x3_bf16x3(B, H, W, Cin, Cout):
     """Dense stride-1 3x3 convolutions in bf16x3 mode run on the halo-staged kernel (k_conv_d3_b3): forward with the full epilogue
@@ -716,6 +733,26 @@ def test_halo_conv3x3_bf16x3(B, H, W, Cin, Cout):
         plain = K.conv_fwd(rows, wk, 9, b.to(DEV), B * H * W, Cout, spec.fwd_ix, stats=stats)
         close(plain, pre_rows, rtol=1e-3, atol=1e-4, what="halo conv fwd")
         assert torch.equal(K.conv_fwd(rows, K.weight_layout_split(wk, Cout, Cin, 9, 0), 9, b.to(DEV), B * H * W, Cout, spec.fwd_ix, w_split=True), plain)
+        if Cout % 32 == 0:
+            # the same convolution with the weights in fragment-major split format (k_conv_d3f_b3: fragments straight from L2, one barrier
+            # per K chunk): same products in the same order -> bit-identical to the LDS-staged kernel, forward, epilogue and data gradient
+            wf = K.weight_layout_split(wk, Cout, Cin, 9, 0, frag=True)
+            assert torch.equal(K.conv_fwd(rows, wf, 9, b.to(DEV), B * H * W, Cout, spec.fwd_ix, w_split=2), plain)
+            outf = K.conv_fwd(rows, wf, 9, b.to(DEV), B * H * W, Cout, spec.fwd_ix, scale=sc.to(DEV), shift=sh.to(DEV), residual=res.to(DEV), relu=True, w_split=2)
+            assert torch.equal(outf, out)
+            statsf = torch.zeros(2 * Cout, device=DEV)
+            K.conv_fwd(rows, wf, 9, b.to(DEV), B * H * W, Cout, spec.fwd_ix, stats=statsf, w_split=2)
+            close(statsf, stats, rtol=1e-5, atol=1e-3)
+            if Cin % 32 == 0 and Cin >= 64:
+                god = go.permute(0, 2, 3, 1).reshape(-1, Cout).contiguous().to(DEV)
+                wd_lds = K.weight_layout_split(wk, Cout, Cin, 9, 2)                    # [Cin][tap][Cout], LDS-staged kernel
+                wd_frag = K.weight_layout_split(wk, Cout, Cin, 9, 2, frag=True)
+                g_lds = K.conv_fwd(god, wd_lds, 9, None, B * H * W, Cin, spec.bwd_ix, w_split=True)
+                g_frag = K.conv_fwd(god, wd_frag, 9, None, B * H * W, Cin, spec.bwd_ix, w_split=2)
+                assert torch.equal(g_frag, g_lds)
+                close(g_frag, xr.grad.permute(0, 2, 3, 1).reshape(-1, Cin), rtol=1e-3, atol=1e-4, what="fragment-major dgrad")
+            # torch-layout sources (Conv2d [Cout][Cin][kh][kw]) through the multi-job conversion give the same operand bytes
+            assert torch.equal(K.weight_layout_split(w.to(DEV).contiguous(), Cout, Cin, 9, 1, frag=True), wf)
         close(stats[:Cout], pre_rows.sum(0), rtol=1e-3, atol=2e-3); close(stats[Cout:], (pre_rows * pre_rows).sum(0), rtol=1e-3, atol=2e-3)
         xd = rows.clone().requires_grad_(True)
         wd = torch.nn.Parameter(w.to(DEV))

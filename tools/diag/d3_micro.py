@@ -24,9 +24,9 @@ def main():
     x = torch.randn(B * H * W, Cin, generator=g).to(dev)
     w = (torch.randn(Cout, 9, Cin, generator=g) / (9 * Cin) ** 0.5).to(dev)
     spec = A.dense_conv_spec(B, H, W, 3, 3, 1, 1)
-    ws = os.environ.get("RD_WS", "1") == "1"
+    ws = int(os.environ.get("RD_WS", "1"))          # 0: fp32 weights, 1: split format (LDS-staged kernel), 2: fragment-major (k_conv_d3f_b3)
     if ws:
-        w = K.weight_layout_split(w, Cout, Cin, 9, 0)
+        w = K.weight_layout_split(w, Cout, Cin, 9, 0, frag=ws == 2)
     for _ in range(3):
         K.conv_fwd(x, w, 9, None, B * H * W, Cout, spec.fwd_ix, w_split=ws)
     torch.cuda.synchronize()
