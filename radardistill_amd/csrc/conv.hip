@@ -264,6 +264,8 @@ static int conv_fwd_impl(const float *in, int in_rows, int Cin, const float *wei
                          const float *residual, int relu, float *stats, int in_split, int w_split, void *stream);
 bool conv_d3f_applies(const ConvArgs &a);                      // conv_d3f.hip
 int launch_conv_d3f_b3(const ConvArgs &a, hipStream_t st);
+bool gemm_b3f_applies(const ConvArgs &a);                      // conv_gemmf.hip
+int launch_gemm_b3f(const ConvArgs &a, hipStream_t st);
 
 extern "C" int rd_conv_fwd(const float *in, int in_rows, int Cin, const float *weight_k, int taps, const float *bias, float *out,
                            int out_rows, int Cout, const rd_conv_index *idx, const float *scale, const float *shift,
@@ -305,10 +307,12 @@ static int conv_fwd_impl(const float *in, int in_rows, int Cin, const float *wei
     hipStream_t st = S(stream);
     dim3 block(256);
     if (w_split == 2) {          // weights in fragment-major split format (RD_LAYOUT_FRAG): only the kernels that read fragments from L2
-        RD_REQUIRE(g_conv_math == 1 && conv_d3f_applies(a),
-                   "rd_conv_fwd_split: fragment-major weights (w_is_split = 2) need bf16x3 mode and a dense stride-1 3x3 convolution with "
-                   "Cin %% 32 == 0, Cout %% 32 == 0, fp32 activations (Cin %d, Cout %d, taps %d, mode %d)", Cin, Cout, taps, idx->mode);
-        launch_conv_d3f_b3(a, st);
+        RD_REQUIRE(g_conv_math == 1 && (conv_d3f_applies(a) || gemm_b3f_applies(a)),
+                   "rd_conv_fwd_split: fragment-major weights (w_is_split = 2) need bf16x3 mode, fp32 activations and either a dense stride-1 "
+                   "3x3 convolution (Cin %% 32 == 0, Cout %% 32 == 0) or a 1-tap GEMM (Cin %% 64 == 0, Cout %% 32 == 0); got Cin %d, Cout %d, "
+                   "taps %d, mode %d", Cin, Cout, taps, idx->mode);
+        if (taps == 1) launch_gemm_b3f(a, st);
+        else launch_conv_d3f_b3(a, st);
         return check_launch("rd_conv_fwd(bf16x3, fragment-major weights)");
     }
     if (g_conv_math == 1 && Cout > 32) {

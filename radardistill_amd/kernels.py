@@ -292,6 +292,7 @@ def weight_layout_split_multi(jobs_dev, chunk_job_dev, chunk_group_dev, n_chunks
           "rd_weight_layout_split_multi")
 
 
+GEMMF = os.environ.get("RD_GEMMF", "1") != "0"      # A/B switch: 1-tap GEMMs on the fragment-major-weights kernel (conv_gemmf.hip)
 D3F = os.environ.get("RD_D3F", "1") != "0"          # A/B switch: dense 3x3 convolutions on the fragment-major-weights kernel (conv_d3f.hip)
 LAYOUT_FRAG = 16                                     # RD_LAYOUT_FRAG of include/rdamd.h
 
@@ -301,6 +302,9 @@ def wants_frag_weights(ix, in_rows, out_rows, Cin, Cout, taps):
     stride-1 3x3 geometry on same-size maps (forward: mode 1, data gradient: mode 2), Cin % 32 == 0, Cout % 32 == 0, and a map large
     enough for 8 x 16-pixel tiles to give every CU a workgroup (smaller maps keep the LDS-staged kernel's 8 x 8 tiles).  Mirrors
     conv_d3f_applies / launch_conv_d3f_b3 (conv_d3f.hip)."""
+    if (GEMMF and taps == 1 and get_conv_math() == "bf16x3" and ix.mode in (1, 2) and ix.KH == 1 and ix.KW == 1 and ix.stride == 1 and ix.pad == 0
+            and ix.Hin == ix.Hout and ix.Win == ix.Wout and in_rows == out_rows and Cin % 64 == 0 and Cout % 32 == 0 and Cout >= 64 and out_rows > 0):
+        return True          # 1-tap GEMM (nn.Linear, 1x1 convolutions, the DCNv2 column GEMM, forward or data gradient): k_gemm_b3f (conv_gemmf.hip)
     if not (D3F and get_conv_math() == "bf16x3" and ix.mode in (1, 2) and taps == 9 and ix.KH == 3 and ix.KW == 3 and ix.stride == 1 and ix.pad == 1
             and ix.Hin == ix.Hout and ix.Win == ix.Wout and Cin % 32 == 0 and Cout % 32 == 0 and Cout >= 64 and in_rows == out_rows):
         return False
@@ -314,6 +318,8 @@ def wants_frag_weights(ix, in_rows, out_rows, Cin, Cout, taps):
 def _kernel_tag(ix, in_rows, out_rows, Cin, Cout, taps, in_split, tile, w_split=0):
     """Which instantiation rd_conv_fwd launches (mirrors the dispatch in conv.hip / conv_b3.hip; used by bench.py's roofline only):
     128 / 64 = gathered implicit-GEMM tile, "d3_128" / "d3_16x64" / "d3_64" = halo-staged dense 3x3 kernel (bf16x3 mode; pre-split weights assumed for the middle one)."""
+    if w_split == 2 and taps == 1:          # k_gemm_b3f (launch_gemm_b3f)
+        return "gemmf_128" if ((out_rows + 127) // 128) * ((Cout + 127) // 128) >= 256 else "gemmf_64"
     if w_split == 2:          # fragment-major weights: k_conv_d3f_b3 (launch_conv_d3f_b3)
         big_rows = (out_rows // (ix.Hout * ix.Wout)) * ((ix.Hout + 7) // 8) * ((ix.Wout + 15) // 16)
         return "d3f_128" if (Cout >= 128 and big_rows * ((Cout + 127) // 128) >= 384) else "d3f_64"

@@ -45,7 +45,10 @@ class _DCNFn(torch.autograd.Function):
             col = K.dcn_columns(x_rows, samp_idx, samp_w)
             lin = A.linear_spec(rows_o).fwd_ix
             if A._b3_wsplit(taps * Cin, Cout):
-                out = K.conv_fwd(col, A.operand_weight_split(weight, Cout, Cin, taps, 1), 1, bias.detach(), rows_o, Cout, lin, w_split=True)
+                # (the fragment-major image of [Cout][taps][Cin] read as a 1-tap GEMM with K = taps * Cin is the same bytes)
+                frag = Cin % 16 == 0 and K.wants_frag_weights(lin, rows_o, rows_o, taps * Cin, Cout, 1)
+                out = K.conv_fwd(col, A.operand_weight_split(weight, Cout, Cin, taps, 1, frag=frag), 1, bias.detach(), rows_o, Cout, lin,
+                                 w_split=2 if frag else True)
             else:
                 out = K.conv_fwd(col, A.kernel_weight(weight, Cout, Cin, taps, 1), 1, bias.detach(), rows_o, Cout, lin)
         else:         # sampling fused into the GEMM's operand staging (index mode 3)

@@ -305,6 +305,55 @@ def test_linear_as_one_tap_conv():
     close(xd.grad, xr.grad); close(ld.weight.grad, lin.weight.grad, atol=2e-4); close(ld.bias.grad, lin.bias.grad, atol=2e-4)
 
 
+@pytest.mark.parametrize("rows,Cin,Cout", [(333, 256, 1024),       # ragged rows, 64-row tiles
+                                           (40000, 64, 128),       # 128 x 128 tiles, one K chunk, ragged last row tile
+                                           (4100, 1024, 256),      # 16 K chunks
+                                           (700, 2304, 64),        # DCNv2 column GEMM depth, 64-column tile
+                                           (129, 128, 96)])        # Cout not a tile multiple
+def test_one_tap_gemm_with_fragment_major_weights(rows, Cin, Cout):
+    """k_gemm_b3f (conv_gemmf.hip): nn.Linear / 1x1 convolutions in bf16x3 mode with the weights read as MFMA fragments straight from
+    L2.  Same products in the same order per accumulator as the gathered kernel -> equal to it bit for bit (forward, full epilogue,
+    statistics to rounding of the atomics), and within 1e-3 of torch's fp32 matmul; forward and data gradient through autograd."""
+    A, K, SP = _mods()
+    rng = np.random.default_rng(rows + Cin)
+    x = torch.from_numpy(rng.normal(size=(rows, Cin)).astype(np.float32))
+    w = torch.from_numpy((rng.normal(size=(Cout, Cin)) / np.sqrt(Cin)).astype(np.float32))
+    b, sc, sh = [torch.from_numpy(rng.normal(size=(Cout,)).astype(np.float32)) for _ in range(3)]
+    res = torch.from_numpy(rng.normal(size=(rows, Cout)).astype(np.float32))
+    go = torch.from_numpy(rng.normal(size=(rows, Cout)).astype(np.float32))
+    pre = x @ w.t() + b
+    spec = A.linear_spec(rows)
+    K.set_conv_math("bf16x3")
+    try:
+        assert K.wants_frag_weights(spec.fwd_ix, rows, rows, Cin, Cout, 1)
+        xd, wk = x.to(DEV), w.to(DEV).view(Cout, 1, Cin).contiguous()
+        w_lds = K.weight_layout_split(wk, Cout, Cin, 1, 0)
+        w_frag = K.weight_layout_split(wk, Cout, Cin, 1, 0, frag=True)
+        kw = dict(scale=sc.to(DEV), shift=sh.to(DEV), residual=res.to(DEV), relu=True)
+        ref = K.conv_fwd(xd, w_lds, 1, b.to(DEV), rows, Cout, spec.fwd_ix, w_split=True, **kw)
+        got = K.conv_fwd(xd, w_frag, 1, b.to(DEV), rows, Cout, spec.fwd_ix, w_split=2, **kw)
+        assert torch.equal(got, ref)
+        close(got, torch.relu(pre * sc + sh + res), rtol=1e-3, atol=1e-4, what="frag gemm + epilogue")
+        stats = torch.zeros(2 * Cout, device=DEV)
+        plain = K.conv_fwd(xd, w_frag, 1, b.to(DEV), rows, Cout, spec.fwd_ix, stats=stats, w_split=2)
+        close(plain, pre, rtol=1e-3, atol=1e-4, what="frag gemm")
+        close(stats[:Cout], pre.sum(0), rtol=1e-3, atol=2e-3 * rows ** 0.5); close(stats[Cout:], (pre * pre).sum(0), rtol=1e-3, atol=2e-3 * rows ** 0.5)
+        # autograd path: forward and data gradient pick the fragment-major operands by themselves
+        xr = x.clone().requires_grad_(True)
+        (torch.nn.functional.linear(xr, w, b) * go).sum().backward()
+        xg = xd.clone().requires_grad_(True)
+        wp, bp = torch.nn.Parameter(w.to(DEV)), torch.nn.Parameter(b.to(DEV))
+        A.begin_step(torch.device(DEV))
+        y = A.conv(xg, wp, bp, spec, Cout)
+        assert torch.equal(y.detach(), plain)
+        (y * go.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+        close(xg.grad, xr.grad, rtol=1e-3, atol=1e-4, what="frag gemm dgrad")
+        close(wp.grad, (go.t() @ x), rtol=1e-3, atol=1e-3 * float((go.t() @ x).abs().max()), what="wgrad next to the frag gemm")
+    finally:
+        K.set_conv_math("f32")
+
+
 def test_conv_epilogue_and_fused_stats():
     A, K, SP = _mods()
     rng = np.random.default_rng(21)

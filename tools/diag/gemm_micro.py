@@ -23,9 +23,9 @@ def main():
     g = torch.Generator(device="cpu").manual_seed(1)
     x = torch.randn(rows, Cin, generator=g).to(dev)
     w = (torch.randn(Cout, 1, Cin, generator=g) / Cin ** 0.5).to(dev)
-    ws = os.environ.get("RD_WS", "1") == "1" and K.get_conv_math() == "bf16x3"
+    ws = int(os.environ.get("RD_WS", "1")) if K.get_conv_math() == "bf16x3" else 0          # 1: split format (gathered kernel), 2: fragment-major (k_gemm_b3f)
     if ws:
-        w = K.weight_layout_split(w, Cout, Cin, 1, 0)
+        w = K.weight_layout_split(w, Cout, Cin, 1, 0, frag=ws == 2)
     spec = A.linear_spec(rows)
     for _ in range(3):
         K.conv_fwd(x, w, 1, None, rows, Cout, spec.fwd_ix, w_split=ws)
