@@ -197,6 +197,12 @@ def cpu_baseline(grid, B=1):
 def kernel_names(b3):
     """instantiation tag (kernels._kernel_tag / conv_wgrad) -> (description, rocprofv3 kernel-name prefix)."""
     names = {
+        "d3f_128": ("k_conv_d3f_b3<8,16,128> (dense stride-1 3x3 conv, forward and data gradient: 8x16-pixel halo double-buffered in LDS, weight "
+                    "fragments straight from L2 in fragment-major split format, one barrier per 32-channel chunk)", "k_conv_d3f_b3<8, 16, 128"),
+        "d3f_64": ("k_conv_d3f_b3<8,16,64> (the same kernel with a 64-channel column tile: the 8192-row maps)", "k_conv_d3f_b3<8, 16, 64"),
+        "gemmf_128": ("k_gemm_b3f<128,128> (1-tap GEMM: nn.Linear / 1x1 conv / DCNv2 column GEMM; activations split once per 64-channel chunk in "
+                      "LDS, weight fragments straight from L2)", "k_gemm_b3f<128"),
+        "gemmf_64": ("k_gemm_b3f<64,*> (1-tap GEMM, 64-row tiles)", "k_gemm_b3f<64"),
         "d3_128": ("k_conv_d3_b3<8,16,128> (dense stride-1 3x3 conv, forward and data gradient: halo-staged 8x16-pixel tile)", "k_conv_d3_b3<8, 16, 128"),
         "d3_16x64": ("k_conv_d3_b3<8,16,64> (dense stride-1 3x3 conv, halo-staged 8x16-pixel x 64-channel tile: the 8192-row maps)", "k_conv_d3_b3<8, 16, 64"),
         "d3_64": ("k_conv_d3_b3<8,8,64> (dense stride-1 3x3 conv, halo-staged 8x8-pixel x 64-channel tile)", "k_conv_d3_b3<8, 8, 64"),

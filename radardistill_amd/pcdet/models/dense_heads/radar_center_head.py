@@ -105,17 +105,18 @@ class _BranchBatch:
         plan.frozen_cache = None
         return plan
 
-    def _frozen_tensors(self):
-        """Teacher: concatenated kernel-layout weights and folded BatchNorm, rebuilt only when a source tensor changes."""
+    def _frozen_tensors(self, frag=False):
+        """Teacher: concatenated kernel-layout weights and folded BatchNorm, rebuilt only when a source tensor changes.
+        frag: the first-stage weights in fragment-major split format (kernels.wants_frag_weights)."""
         from radardistill_amd import kernels as K
         src = [t for (_, _, c1, bn, c2, _) in self.branches for t in (c1.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, c2.weight, c2.bias)]
         b3 = K.get_conv_math() == "bf16x3"
-        ver = (tuple(t._version for t in src), src[0].data_ptr(), b3)
+        ver = (tuple(t._version for t in src), src[0].data_ptr(), b3, bool(frag), A._FROZEN_EPOCH[0])
         if self.frozen_cache is None or self.frozen_cache[0] != ver:
             with torch.no_grad():
                 w1 = torch.cat([b[2].weight for b in self.branches], 0).contiguous()
                 # bf16x3: the operand is kept pre-split like every other frozen weight (the in-kernel split made this one launch 3x slower)
-                w1k = K.weight_layout_split(w1, w1.shape[0], 64, 9, 1) if b3 else K.weight_layout(w1, w1.shape[0], 64, 9, 1)
+                w1k = K.weight_layout_split(w1, w1.shape[0], 64, 9, 1, frag=frag) if b3 else K.weight_layout(w1, w1.shape[0], 64, 9, 1)
                 b1 = torch.cat([b[2].bias for b in self.branches]) if self.branches[0][2].bias is not None else None
                 rstd = torch.rsqrt(torch.cat([b[3].running_var for b in self.branches]) + self.branches[0][3].eps)
                 scale = (torch.cat([b[3].weight for b in self.branches]) * rstd).contiguous()
@@ -156,9 +157,10 @@ class _BranchBatch:
             flags = self._frozen_flag = (training, not any(p.requires_grad for b in self.branches for m in b[2:5] for p in m.parameters()))
         params_frozen = flags[1]
         if (not torch.is_grad_enabled() or (params_frozen and not rows.requires_grad)) and not training:
-            w1k, b1, scale, shift, w2, b2 = self._frozen_tensors()
+            frag = K.wants_frag_weights(spec.fwd_ix, rows.shape[0], rows.shape[0], 64, C1, 9)
+            w1k, b1, scale, shift, w2, b2 = self._frozen_tensors(frag)
             y = K.conv_fwd(rows, w1k, 9, b1, rows.shape[0], C1, spec.fwd_ix, scale=scale, shift=shift, relu=True,
-                           w_split=K.get_conv_math() == "bf16x3")
+                           w_split=2 if frag else K.get_conv_math() == "bf16x3")
             out = K.nconv_fwd(y, w2, b2, B, H, W, self.tab)
         elif training:
             # parameters of the 42 branches concatenated: persistent leaves whose gradients are handed to the branch parameters as
