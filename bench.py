@@ -201,8 +201,11 @@ def kernel_names(b3):
                     "fragments straight from L2 in fragment-major split format, one barrier per 32-channel chunk)", "k_conv_d3f_b3<8, 16, 128"),
         "d3f_64": ("k_conv_d3f_b3<8,16,64> (the same kernel with a 64-channel column tile: the 8192-row maps)", "k_conv_d3f_b3<8, 16, 64"),
         "gemmf_128": ("k_gemm_b3f<128,128> (1-tap GEMM: nn.Linear / 1x1 conv / DCNv2 column GEMM; activations split once per 64-channel chunk in "
-                      "LDS, weight fragments straight from L2)", "k_gemm_b3f<128"),
-        "gemmf_64": ("k_gemm_b3f<64,*> (1-tap GEMM, 64-row tiles)", "k_gemm_b3f<64"),
+                      "LDS, weight fragments straight from L2)", "k_gemm_b3f<128, 128, false"),
+        "sparsef_128": ("k_gemm_b3f<128,*,table> (sparse convolution over a neighbour table: gathered 64-channel chunks split once in LDS, weight "
+                        "fragments straight from L2)", "k_gemm_b3f<128, 128, true"),
+        "sparsef_64": ("k_gemm_b3f<64,*,table> (sparse convolution over a neighbour table, 64-row tiles)", "k_gemm_b3f<64, 128, true"),
+        "gemmf_64": ("k_gemm_b3f<64,*> (1-tap GEMM, 64-row tiles)", "k_gemm_b3f<64, 128, false"),
         "d3_128": ("k_conv_d3_b3<8,16,128> (dense stride-1 3x3 conv, forward and data gradient: halo-staged 8x16-pixel tile)", "k_conv_d3_b3<8, 16, 128"),
         "d3_16x64": ("k_conv_d3_b3<8,16,64> (dense stride-1 3x3 conv, halo-staged 8x16-pixel x 64-channel tile: the 8192-row maps)", "k_conv_d3_b3<8, 16, 64"),
         "d3_64": ("k_conv_d3_b3<8,8,64> (dense stride-1 3x3 conv, halo-staged 8x8-pixel x 64-channel tile)", "k_conv_d3_b3<8, 8, 64"),

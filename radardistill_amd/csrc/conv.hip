@@ -309,9 +309,9 @@ static int conv_fwd_impl(const float *in, int in_rows, int Cin, const float *wei
     if (w_split == 2) {          // weights in fragment-major split format (RD_LAYOUT_FRAG): only the kernels that read fragments from L2
         RD_REQUIRE(g_conv_math == 1 && (conv_d3f_applies(a) || gemm_b3f_applies(a)),
                    "rd_conv_fwd_split: fragment-major weights (w_is_split = 2) need bf16x3 mode, fp32 activations and either a dense stride-1 "
-                   "3x3 convolution (Cin %% 32 == 0, Cout %% 32 == 0) or a 1-tap GEMM (Cin %% 64 == 0, Cout %% 32 == 0); got Cin %d, Cout %d, "
+                   "3x3 convolution (Cin %% 32 == 0, Cout %% 32 == 0) or a 1-tap GEMM / neighbour-table convolution (Cin %% 64 == 0, Cout %% 32 == 0); got Cin %d, Cout %d, "
                    "taps %d, mode %d", Cin, Cout, taps, idx->mode);
-        if (taps == 1) launch_gemm_b3f(a, st);
+        if (idx->mode == 0 || taps == 1) launch_gemm_b3f(a, st);
         else launch_conv_d3f_b3(a, st);
         return check_launch("rd_conv_fwd(bf16x3, fragment-major weights)");
     }

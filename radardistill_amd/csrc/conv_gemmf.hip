@@ -12,6 +12,11 @@
 //   * schedule pinned with sched_barrier (see conv_d3f.hip).
 // Same epilogue contract as k_conv_igemm_b3 (bias, BatchNorm statistics, scale / shift, residual, ReLU); products and their order per
 // accumulator are those of the other bf16x3 kernels (lo*hi, hi*lo, hi*hi; K ascending).
+//
+// TABLE = true: the same kernel as a SPARSE convolution over a neighbour table (index mode 0: SubMConv2d, SparseConv2d and their data
+// gradients).  K runs over (tap, 64-channel block); the A tile of a chunk is GATHERED -- row j of the tile comes from input row
+// nbr[j][tap] (or is zero).  The tile's slice of the table is read into LDS once (coalesced), taps without any source row in the tile
+// are skipped, and a tap costs Cin / 64 barriers instead of the Cin / 32 x (gather -> LDS -> barrier) steps of k_conv_igemm_b3.
 #include <stdlib.h>
 #include "conv_common.hpp"
 
@@ -34,13 +39,15 @@ __device__ __forceinline__ void split4(const f32x4 v, bf16x4 &hi, bf16x4 &lo) {
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool TABLE>
 __global__ __launch_bounds__(256, 2) void k_gemm_b3f(const ConvArgs a) {
     constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
     constexpr int PART = BM * GROW;                    // bf16 elements of one (hi or lo) tile image
     constexpr int AL = BM * (GK / 4) / 256;            // float4 activation loads per thread and chunk (BM rows x 16 pieces)
     static_assert(MI >= 1 && NI >= 1 && AL >= 1, "wave tile at least 32x32");
     __shared__ __attribute__((aligned(16))) __bf16 lds[2 * 2 * PART];          // [buffer][hi | lo][row][72]
+    __shared__ int s_nbr[TABLE ? BM * MAX_TAPS : 1];                             // TABLE: this tile's rows of the neighbour table
+    __shared__ int s_mask;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -48,7 +55,27 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3f(const ConvArgs a) {
     if (!xcd_tile((a.out_rows + BM - 1) / BM, (a.Cout + BN - 1) / BN, row_tile, col_tile)) return;
     const int m0 = row_tile * BM, n0 = col_tile * BN;
     const int fr = lane & 31, fh = lane >> 5;
-    const int kchunks = a.Cin / GK, c16n = a.Cin >> 4;
+    const int cblocks = a.Cin / GK, c16n = a.Cin >> 4;          // 64-channel blocks per tap; k16 blocks per tap
+
+    // ---- TABLE: stage the table slice, find the taps that have a source row in this tile
+    int tapmask = 1;
+    if constexpr (TABLE) {
+        if (tid == 0) s_mask = 0;
+        const int n_ent = min(BM, a.out_rows - m0) * a.taps;
+        const int *tab = a.ix.nbr + (int64_t)m0 * a.taps;
+        int mine = 0;
+        for (int e = tid; e < BM * a.taps; e += 256) {
+            const int v = e < n_ent ? tab[e] : -1;
+            s_nbr[e] = v;
+            if (v >= 0) mine |= 1 << (e % a.taps);
+        }
+        __syncthreads();
+        if (mine) atomicOr(&s_mask, mine);
+        __syncthreads();
+        tapmask = __builtin_amdgcn_readfirstlane(s_mask);          // bit t = stored column t of the table (the flipped order is applied when a tap is walked); uniform -> scalar registers
+    }
+    const int ntaps_on = TABLE ? __popc(tapmask) : 1;
+    const int kchunks = ntaps_on * cblocks;
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -66,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3f(const ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int nb = min((n0 + wn * WN + j * 32) >> 5, (a.Cout >> 5) - 1);
-        wbase[j] = nb * c16n * 128 + lane;
+        wbase[j] = nb * (TABLE ? a.taps : 1) * c16n * 128 + lane;
     }
 
     struct BSet {
@@ -113,19 +140,40 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3f(const ConvArgs a) {
             for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[i], bh[j], acc[i][j], 0, 0, 0);
     };
 
-    // activation staging: piece e = tid + 256 q of the tile = (row e >> 4, channels 4 (e & 15) .. +3); rows past the end read the last row
-    // and are zeroed when split (never stored either)
+    // activation staging: piece e = tid + 256 q of the tile = (row e >> 4, channels 4 (e & 15) .. +3).  Rows without a source (past the
+    // end; TABLE: no neighbour at this tap) read a clamped, readable row and are zeroed when split (a select right after the load would
+    // wait for it there and then).
     f32x4 ra[AL];
-    int64_t goff[AL];
-    int okmask = 0;
+    int goff[AL];          // element offsets (the launcher checks rows * Cin < 2^31)
+    int okmask = 0, ok_next = 0;
+    // chunk walk: chunk c = (c / cblocks)-th set tap, 64-channel block c % cblocks; w16 = k16 block of the chunk's first half-step in the
+    // fragment-major weight image (tap * c16n + 4 * block)
+    int walk_mask = tapmask, walk_cb = 0, walk_tap = 0;
+    auto next_chunk = [&](int &w16, int &kc) {          // -> true when the chunk starts a new tap (source rows change)
+        const bool new_tap = walk_cb == 0;
+        if (new_tap) {
+            walk_tap = TABLE ? __ffs(walk_mask) - 1 : 0;
+            walk_mask &= walk_mask - 1;
+        }
+        const int wt = TABLE ? (a.ix.flip ? a.taps - 1 - walk_tap : walk_tap) : 0;          // weight tap of stored table column walk_tap
+        w16 = wt * c16n + 4 * walk_cb;
+        kc = walk_cb * GK;
+        if (++walk_cb == cblocks) walk_cb = 0;
+        return new_tap;
+    };
+    auto load_A = [&](bool new_tap, int kc) {
+        if (new_tap) {
+            ok_next = 0;
 #pragma unroll
-    for (int q = 0; q < AL; ++q) {
-        const int e = tid + 256 * q;
-        const int r = m0 + (e >> 4);
-        if (r < a.out_rows) okmask |= 1 << q;
-        goff[q] = (int64_t)min(r, a.out_rows - 1) * a.Cin + 4 * (e & 15);
-    }
-    auto load_A = [&](int kc) {
+            for (int q = 0; q < AL; ++q) {
+                const int e = tid + 256 * q;
+                int src;
+                if constexpr (TABLE) src = s_nbr[(e >> 4) * a.taps + walk_tap];
+                else src = (m0 + (e >> 4) < a.out_rows) ? m0 + (e >> 4) : -1;
+                if (src >= 0) ok_next |= 1 << q;
+                goff[q] = max(src, 0) * a.Cin + 4 * (e & 15);
+            }
+        }
 #pragma unroll
         for (int q = 0; q < AL; ++q) ra[q] = *reinterpret_cast<const f32x4 *>(a.in + goff[q] + kc);
     };
@@ -142,31 +190,43 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3f(const ConvArgs a) {
         }
     };
 
-    const int n_half = 4 * kchunks;          // k16 half-steps in total
-    load_A(0);
-    load_B(Bq[0], 0);
-    load_B(Bq[1], 1);
-    load_B(Bq[2], 2);
-    store_A(0);
+    // ---- pipeline.  Weight fragments: ring of four register sets, half-step H (chunk H / 4, k16 slice H % 4) is requested three half-
+    // steps ahead; w16_cur / w16_nxt = first k16 block of the current / next chunk.  Activations: the next chunk's tile is requested at
+    // half-step 0 (after that half-step's weight request) and split into the other LDS buffer after half-step 2.
+    int w16_cur = 0, w16_nxt = 0, kc_nxt = 0;
+    if (kchunks > 0) {
+        const bool nt = next_chunk(w16_cur, kc_nxt);
+        load_A(nt, kc_nxt);
+        okmask = ok_next;
+        load_B(Bq[0], w16_cur);
+        load_B(Bq[1], w16_cur + 1);
+        load_B(Bq[2], w16_cur + 2);
+        store_A(0);
+    }
     __syncthreads();
     for (int kq = 0; kq < kchunks; ++kq) {
         const bool more = kq + 1 < kchunks;
         const __bf16 *Abuf = lds + (kq & 1) * 2 * PART;
+        bool nt = false;
+        if (more) nt = next_chunk(w16_nxt, kc_nxt);
         read_A(Aq[0], Abuf, 0);
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            const int hn = 4 * kq + h + 3;          // weight fragments of half-step hn: requested three half-steps ahead
-            if (hn < n_half) load_B(Bq[(h + 3) & 3], hn);
-            if (h == 0 && more) load_A((kq + 1) * GK);          // after this half-step's weight request
+            // half-step h + 3: slice 3 of this chunk (h == 0) or slice h - 1 of the next one
+            if (h == 0) load_B(Bq[3], w16_cur + 3);
+            else if (more) load_B(Bq[(h + 3) & 3], w16_nxt + h - 1);
+            if (h == 0 && more) load_A(nt, kc_nxt);          // after this half-step's weight request
             if (h + 1 < 4) read_A(Aq[(h + 1) & 1], Abuf, h + 1);
             __builtin_amdgcn_sched_barrier(0);
             mfmas(Aq[h & 1], Bq[h & 3]);
             __builtin_amdgcn_sched_barrier(0);
             if (h == 2 && more) {
+                okmask = ok_next;
                 store_A((kq + 1) & 1);          // the other buffer: last read before the previous chunk's closing barrier
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        w16_cur = w16_nxt;
         __syncthreads();
     }
 
@@ -219,26 +279,37 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3f(const ConvArgs a) {
 
 }  // namespace
 
-// 1-tap dense geometry whose source row is the output row (nn.Linear and 1x1 stride-1 convolutions, forward or data gradient),
-// fp32 activations, Cin % 64 == 0, Cout % 32 == 0.  Mirrored by kernels.py::wants_frag_weights.
+// Shapes the kernel takes (mirrored by kernels.py::wants_frag_weights): fp32 activations, Cin % 64 == 0, Cout % 32 == 0 and
+//   * 1-tap dense geometry whose source row is the output row (nn.Linear and 1x1 stride-1 convolutions, forward or data gradient), or
+//   * a neighbour table (index mode 0), up to MAX_TAPS taps.
 bool gemm_b3f_applies(const ConvArgs &a) {
     const rd_conv_index &ix = a.ix;
+    if (a.in_split || a.Cin % GK != 0 || a.Cout % 32 != 0 || a.out_rows <= 0) return false;
+    if ((int64_t)max(a.in_rows, 1) * a.Cin >= (int64_t)1 << 31) return false;          // 32-bit element offsets in the kernel
+    if (ix.mode == 0) return a.taps >= 1 && a.taps <= MAX_TAPS && (ix.nbr != nullptr || a.out_rows == 0);
     if (a.taps != 1 || !(ix.mode == 1 || ix.mode == 2) || ix.KH != 1 || ix.KW != 1 || ix.stride != 1 || ix.pad != 0) return false;
-    if (ix.Hin != ix.Hout || ix.Win != ix.Wout || a.in_rows != a.out_rows) return false;
-    return !a.in_split && a.Cin % GK == 0 && a.Cout % 32 == 0 && a.out_rows > 0;
+    return ix.Hin == ix.Hout && ix.Win == ix.Wout && a.in_rows == a.out_rows;
 }
 
-int launch_gemm_b3f(const ConvArgs &a, hipStream_t st) {
+template <bool TABLE>
+static void launch_gemm_tiles(const ConvArgs &a, hipStream_t st) {
     dim3 block(256);
     static const int tile_env = getenv("RD_GEMMF_TILE") ? atoi(getenv("RD_GEMMF_TILE")) : 0;          // diagnostic: 128 / 64 forces the row tile
     const int64_t big = cdiv(a.out_rows, 128) * cdiv(a.Cout, 128);
-    const bool bm128 = tile_env ? tile_env == 128 : big >= 256;
+    const bool bm128 = tile_env ? tile_env == 128 : big >= (TABLE ? 384 : 256);
     if (a.Cout >= 128) {
-        if (bm128) k_gemm_b3f<128, 128><<<dim3(xcd_grid(cdiv(a.out_rows, 128), cdiv(a.Cout, 128))), block, 0, st>>>(a);
-        else k_gemm_b3f<64, 128><<<dim3(xcd_grid(cdiv(a.out_rows, 64), cdiv(a.Cout, 128))), block, 0, st>>>(a);
+        if (bm128) k_gemm_b3f<128, 128, TABLE><<<dim3(xcd_grid(cdiv(a.out_rows, 128), cdiv(a.Cout, 128))), block, 0, st>>>(a);
+        else k_gemm_b3f<64, 128, TABLE><<<dim3(xcd_grid(cdiv(a.out_rows, 64), cdiv(a.Cout, 128))), block, 0, st>>>(a);
     } else {
-        if (bm128) k_gemm_b3f<128, 64><<<dim3(xcd_grid(cdiv(a.out_rows, 128), cdiv(a.Cout, 64))), block, 0, st>>>(a);
-        else k_gemm_b3f<64, 64><<<dim3(xcd_grid(cdiv(a.out_rows, 64), cdiv(a.Cout, 64))), block, 0, st>>>(a);
+        if (bm128) k_gemm_b3f<128, 64, TABLE><<<dim3(xcd_grid(cdiv(a.out_rows, 128), cdiv(a.Cout, 64))), block, 0, st>>>(a);
+        else k_gemm_b3f<64, 64, TABLE><<<dim3(xcd_grid(cdiv(a.out_rows, 64), cdiv(a.Cout, 64))), block, 0, st>>>(a);
     }
+}
+
+int launch_gemm_b3f(const ConvArgs &a_in, hipStream_t st) {
+    ConvArgs a = a_in;
+    if (a.in_rows == 0) a.in = a.w;          // "no source" pieces read row 0 and are discarded: keep that address readable
+    if (a.ix.mode == 0) launch_gemm_tiles<true>(a, st);
+    else launch_gemm_tiles<false>(a, st);
     return RD_OK;
 }

@@ -292,6 +292,7 @@ def weight_layout_split_multi(jobs_dev, chunk_job_dev, chunk_group_dev, n_chunks
           "rd_weight_layout_split_multi")
 
 
+SPARSEF = os.environ.get("RD_SPARSEF", "1") != "0"  # A/B switch: sparse (neighbour-table) convolutions on k_gemm_b3f<.., TABLE>
 GEMMF = os.environ.get("RD_GEMMF", "1") != "0"      # A/B switch: 1-tap GEMMs on the fragment-major-weights kernel (conv_gemmf.hip)
 D3F = os.environ.get("RD_D3F", "1") != "0"          # A/B switch: dense 3x3 convolutions on the fragment-major-weights kernel (conv_d3f.hip)
 LAYOUT_FRAG = 16                                     # RD_LAYOUT_FRAG of include/rdamd.h
@@ -305,6 +306,9 @@ def wants_frag_weights(ix, in_rows, out_rows, Cin, Cout, taps):
     if (GEMMF and taps == 1 and get_conv_math() == "bf16x3" and ix.mode in (1, 2) and ix.KH == 1 and ix.KW == 1 and ix.stride == 1 and ix.pad == 0
             and ix.Hin == ix.Hout and ix.Win == ix.Wout and in_rows == out_rows and Cin % 64 == 0 and Cout % 32 == 0 and Cout >= 64 and out_rows > 0):
         return True          # 1-tap GEMM (nn.Linear, 1x1 convolutions, the DCNv2 column GEMM, forward or data gradient): k_gemm_b3f (conv_gemmf.hip)
+    if ix.mode == 0:          # neighbour table (SubMConv2d / SparseConv2d, forward or data gradient): the gathered form of k_gemm_b3f
+        return (SPARSEF and get_conv_math() == "bf16x3" and 1 <= taps <= 16 and Cin % 64 == 0 and Cout % 32 == 0 and Cout >= 64 and out_rows > 0
+                and max(in_rows, 1) * Cin < 2 ** 31)
     if not (D3F and get_conv_math() == "bf16x3" and ix.mode in (1, 2) and taps == 9 and ix.KH == 3 and ix.KW == 3 and ix.stride == 1 and ix.pad == 1
             and ix.Hin == ix.Hout and ix.Win == ix.Wout and Cin % 32 == 0 and Cout % 32 == 0 and Cout >= 64 and in_rows == out_rows):
         return False
@@ -318,6 +322,8 @@ def wants_frag_weights(ix, in_rows, out_rows, Cin, Cout, taps):
 def _kernel_tag(ix, in_rows, out_rows, Cin, Cout, taps, in_split, tile, w_split=0):
     """Which instantiation rd_conv_fwd launches (mirrors the dispatch in conv.hip / conv_b3.hip; used by bench.py's roofline only):
     128 / 64 = gathered implicit-GEMM tile, "d3_128" / "d3_16x64" / "d3_64" = halo-staged dense 3x3 kernel (bf16x3 mode; pre-split weights assumed for the middle one)."""
+    if w_split == 2 and ix.mode == 0:          # k_gemm_b3f<.., TABLE> (launch_gemm_b3f)
+        return "sparsef_128" if ((out_rows + 127) // 128) * ((Cout + 127) // 128) >= 384 else "sparsef_64"
     if w_split == 2 and taps == 1:          # k_gemm_b3f (launch_gemm_b3f)
         return "gemmf_128" if ((out_rows + 127) // 128) * ((Cout + 127) // 128) >= 256 else "gemmf_64"
     if w_split == 2:          # fragment-major weights: k_conv_d3f_b3 (launch_conv_d3f_b3)

@@ -240,6 +240,49 @@ def test_sparse_conv_forward_and_backward(Cin, Cout):
         close(conv.bias.grad, br.grad, atol=2e-4, what="bias grad")
 
 
+@pytest.mark.parametrize("Cin,Cout,n", [(64, 128, 700), (128, 128, 2500), (256, 256, 150), (64, 64, 5000), (128, 96, 1)])
+def test_sparse_conv_fragment_major_kernel_bf16x3(Cin, Cout, n, monkeypatch):
+    """Sparse convolutions (SubMConv2d and the strided SparseConv2d, forward and data gradient) in bf16x3 mode on k_gemm_b3f<.., TABLE>
+    (conv_gemmf.hip): the tile's slice of the neighbour table staged in LDS, gathered 64-channel chunks, weight fragments from L2.
+    Same products in the same order per accumulator as the gathered kernel k_conv_igemm_b3 -> bit-identical to it (RD_SPARSEF = 0 / 1),
+    and within 1e-3 of the oracle's pair-list convolution."""
+    A, K, SP = _mods()
+    rng = np.random.default_rng(Cin + Cout + n)
+    B, H, W = 2, 60, 56
+    idx = rand_sites(rng, B, H, W, n)
+    feats = torch.from_numpy(rng.normal(size=(n, Cin)).astype(np.float32))
+    w = torch.from_numpy((rng.normal(size=(Cout, 3, 3, Cin)) / np.sqrt(9 * Cin)).astype(np.float32))
+    b = torch.from_numpy(rng.normal(size=(Cout,)).astype(np.float32))
+    K.set_conv_math("bf16x3")
+    try:
+        for subm in (True, False):
+            res = {}
+            for on in (False, True):
+                monkeypatch.setattr(K, "SPARSEF", on)
+                conv = (SP.SubMConv2d if subm else SP.SparseConv2d)(Cin, Cout, 3, stride=1 if subm else 2, padding=1, bias=True).to(DEV)
+                with torch.no_grad():
+                    conv.weight.copy_(w); conv.bias.copy_(b)
+                fd = feats.to(DEV).requires_grad_(True)
+                A.begin_step(torch.device(DEV))
+                out = conv(SP.SparseConvTensor(fd, torch.from_numpy(idx).to(DEV), [H, W], B))
+                g = np.random.default_rng(7)
+                go = torch.from_numpy(g.normal(size=tuple(out.features.shape)).astype(np.float32))
+                (out.features * go.to(DEV)).sum().backward()
+                torch.cuda.synchronize()
+                res[on] = (out.features.detach().clone(), fd.grad.clone(), conv.weight.grad.clone(), go)
+            assert torch.equal(res[True][0], res[False][0]), f"forward differs from the gathered kernel (subm={subm})"
+            assert torch.equal(res[True][1], res[False][1]), f"data gradient differs from the gathered kernel (subm={subm})"
+            fr = feats.clone().requires_grad_(True); wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+            nbr = osp.subm_rulebook(idx, (H, W)) if subm else osp.strided_rulebook(idx, (H, W))[2]
+            ref = osp.sparse_conv(fr, nbr, wr, br)
+            (ref * res[True][3]).sum().backward()
+            close(res[True][0], ref, what=f"fwd subm={subm}")
+            close(res[True][1], fr.grad, what="dgrad")
+            close(res[True][2], wr.grad, atol=2e-4, what="wgrad")
+    finally:
+        K.set_conv_math("f32")
+
+
 @pytest.mark.parametrize("Cin,Cout,k,s,p,H,W", [(256, 256, 3, 1, 1, 12, 10), (256, 256, 3, 2, 1, 13, 11), (512, 256, 1, 1, 0, 9, 9),
                                                  (64, 2, 3, 1, 1, 8, 8), (256, 27, 3, 2, 1, 16, 16)])
 def test_dense_conv2d_forward_and_backward(Cin, Cout, k, s, p, H, W):

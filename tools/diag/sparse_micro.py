@@ -30,9 +30,9 @@ def main():
     spec = t._level.subm_spec()
     g = torch.Generator(device="cpu").manual_seed(1)
     w = (torch.randn(Cout, 9, Cin, generator=g) / (9 * Cin) ** 0.5).to(dev)
-    ws = K.get_conv_math() == "bf16x3" and Cout > 32
+    ws = int(os.environ.get("RD_WS", "1")) if (K.get_conv_math() == "bf16x3" and Cout > 32) else 0          # 2: fragment-major (k_gemm_b3f<.., TABLE>)
     if ws:
-        w = K.weight_layout_split(w, Cout, Cin, 9, 0)
+        w = K.weight_layout_split(w, Cout, Cin, 9, 0, frag=ws == 2)
     x = t.features
     pairs = int((spec.fwd_nbr >= 0).sum())
 
