@@ -29,6 +29,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GK = 64;       // channels per K chunk (four k16 half-steps)
 constexpr int GROW = 72;     // bf16 elements per LDS row: 64 data + 8 pad = 144 bytes
+constexpr int TABLE_TAPS = 9;     // neighbour tables are 3x3 (a 128-row tile's slice + two 36-KiB tile buffers still let two workgroups share a CU)
 
 __device__ __forceinline__ void split4(const f32x4 v, bf16x4 &hi, bf16x4 &lo) {
 #pragma unroll
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3f(const ConvArgs a) {
     constexpr int AL = BM * (GK / 4) / 256;            // float4 activation loads per thread and chunk (BM rows x 16 pieces)
     static_assert(MI >= 1 && NI >= 1 && AL >= 1, "wave tile at least 32x32");
     __shared__ __attribute__((aligned(16))) __bf16 lds[2 * 2 * PART];          // [buffer][hi | lo][row][72]
-    __shared__ int s_nbr[TABLE ? BM * MAX_TAPS : 1];                             // TABLE: this tile's rows of the neighbour table
+    __shared__ int s_nbr[TABLE ? BM * TABLE_TAPS : 1];                           // TABLE: this tile's rows of the neighbour table
     __shared__ int s_mask;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -67,12 +68,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3f(const ConvArgs a) {
         for (int e = tid; e < BM * a.taps; e += 256) {
             const int v = e < n_ent ? tab[e] : -1;
             s_nbr[e] = v;
-            if (v >= 0) mine |= 1 << (e % a.taps);
+            // bit = WEIGHT tap of the table column (data gradient: columns are walked mirrored, so that K runs over ascending weight
+            // taps exactly as in k_conv_igemm_b3)
+            if (v >= 0) mine |= 1 << (a.ix.flip ? a.taps - 1 - e % a.taps : e % a.taps);
         }
         __syncthreads();
         if (mine) atomicOr(&s_mask, mine);
         __syncthreads();
-        tapmask = __builtin_amdgcn_readfirstlane(s_mask);          // bit t = stored column t of the table (the flipped order is applied when a tap is walked); uniform -> scalar registers
+        tapmask = __builtin_amdgcn_readfirstlane(s_mask);          // bit t = weight tap t has a source row in this tile; uniform -> scalar registers
     }
     const int ntaps_on = TABLE ? __popc(tapmask) : 1;
     const int kchunks = ntaps_on * cblocks;
@@ -155,8 +158,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3f(const ConvArgs a) {
             walk_tap = TABLE ? __ffs(walk_mask) - 1 : 0;
             walk_mask &= walk_mask - 1;
         }
-        const int wt = TABLE ? (a.ix.flip ? a.taps - 1 - walk_tap : walk_tap) : 0;          // weight tap of stored table column walk_tap
-        w16 = wt * c16n + 4 * walk_cb;
+        w16 = walk_tap * c16n + 4 * walk_cb;          // walk_tap = weight tap
         kc = walk_cb * GK;
         if (++walk_cb == cblocks) walk_cb = 0;
         return new_tap;
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3f(const ConvArgs a) {
             for (int q = 0; q < AL; ++q) {
                 const int e = tid + 256 * q;
                 int src;
-                if constexpr (TABLE) src = s_nbr[(e >> 4) * a.taps + walk_tap];
+                if constexpr (TABLE) src = s_nbr[(e >> 4) * a.taps + (a.ix.flip ? a.taps - 1 - walk_tap : walk_tap)];
                 else src = (m0 + (e >> 4) < a.out_rows) ? m0 + (e >> 4) : -1;
                 if (src >= 0) ok_next |= 1 << q;
                 goff[q] = max(src, 0) * a.Cin + 4 * (e & 15);
@@ -281,12 +283,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3f(const ConvArgs a) {
 
 // Shapes the kernel takes (mirrored by kernels.py::wants_frag_weights): fp32 activations, Cin % 64 == 0, Cout % 32 == 0 and
 //   * 1-tap dense geometry whose source row is the output row (nn.Linear and 1x1 stride-1 convolutions, forward or data gradient), or
-//   * a neighbour table (index mode 0), up to MAX_TAPS taps.
+//   * a neighbour table (index mode 0), up to 9 taps.
 bool gemm_b3f_applies(const ConvArgs &a) {
     const rd_conv_index &ix = a.ix;
     if (a.in_split || a.Cin % GK != 0 || a.Cout % 32 != 0 || a.out_rows <= 0) return false;
     if ((int64_t)max(a.in_rows, 1) * a.Cin >= (int64_t)1 << 31) return false;          // 32-bit element offsets in the kernel
-    if (ix.mode == 0) return a.taps >= 1 && a.taps <= MAX_TAPS && (ix.nbr != nullptr || a.out_rows == 0);
+    if (ix.mode == 0) return a.taps >= 1 && a.taps <= TABLE_TAPS && ix.nbr != nullptr;
     if (a.taps != 1 || !(ix.mode == 1 || ix.mode == 2) || ix.KH != 1 || ix.KW != 1 || ix.stride != 1 || ix.pad != 0) return false;
     return ix.Hin == ix.Hout && ix.Win == ix.Wout && a.in_rows == a.out_rows;
 }

@@ -307,7 +307,7 @@ def wants_frag_weights(ix, in_rows, out_rows, Cin, Cout, taps):
             and ix.Hin == ix.Hout and ix.Win == ix.Wout and in_rows == out_rows and Cin % 64 == 0 and Cout % 32 == 0 and Cout >= 64 and out_rows > 0):
         return True          # 1-tap GEMM (nn.Linear, 1x1 convolutions, the DCNv2 column GEMM, forward or data gradient): k_gemm_b3f (conv_gemmf.hip)
     if ix.mode == 0:          # neighbour table (SubMConv2d / SparseConv2d, forward or data gradient): the gathered form of k_gemm_b3f
-        return (SPARSEF and get_conv_math() == "bf16x3" and 1 <= taps <= 16 and Cin % 64 == 0 and Cout % 32 == 0 and Cout >= 64 and out_rows > 0
+        return (SPARSEF and get_conv_math() == "bf16x3" and 1 <= taps <= 9 and ix.nbr and Cin % 64 == 0 and Cout % 32 == 0 and Cout >= 64 and out_rows > 0
                 and max(in_rows, 1) * Cin < 2 ** 31)
     if not (D3F and get_conv_math() == "bf16x3" and ix.mode in (1, 2) and taps == 9 and ix.KH == 3 and ix.KW == 3 and ix.stride == 1 and ix.pad == 1
             and ix.Hin == ix.Hout and ix.Win == ix.Wout and Cin % 32 == 0 and Cout % 32 == 0 and Cout >= 64 and in_rows == out_rows):
