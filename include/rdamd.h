@@ -206,6 +206,28 @@ int rd_conv_fwd_split(const void *in, int in_is_split, int in_rows, int Cin, con
 int rd_conv_wgrad_split(const void *in, int in_is_split, int in_rows, int Cin, const void *grad_out, int go_is_split, int out_rows,
                         int Cout, int taps, const rd_conv_index *idx, float *grad_wk, void *stream);
 
+/* COMPOSITE calls: convolution (+ bias) -> train-mode BatchNorm (batch statistics from the convolution's epilogue) -> (+ residual) ->
+ * activation, one call per layer and direction -- exactly the launches of rd_conv_fwd[_split] + rd_bn_train_fwd (forward) and
+ * rd_bn_bwd + data gradient + rd_conv_wgrad (backward), in that order, without the host work between them.
+ * w_format: 0 = fp32 kernel layout (rd_conv_fwd / rd_conv_dgrad: the data gradient reads the FORWARD weights transposed),
+ *           1 = split format, 2 = fragment-major split format (rd_conv_fwd_split; backward: the [Cin][taps][Cout] operand).
+ * stats (2 * Cout) and grad_gamma_beta (2 * Cout: [grad_gamma | grad_beta]) and grad_wk (Cout * taps * Cin) accumulate: zero-filled by
+ * the caller.  side (4 * Cout) = [mean | rstd | scale | shift] written by the forward, read by the backward.  grad_in = NULL skips
+ * the data gradient, grad_wk = NULL the weight gradient; side_stream = NULL keeps the weight gradient on main_stream, otherwise it
+ * is launched on side_stream after that stream has been made to wait for main_stream (rd_stream_fork).  ev_*: optional hipEvent_t
+ * handles recorded before / after the convolution launches on the stream they go to (NULL = none).
+ * Replaces one PillarRes18 / DenseEnc / CMA layer of the reference: spconv or nn.Conv2d + nn.BatchNorm + ReLU / GELU
+ * (pcdet/models/backbones_3d/spconv_backbone_2d.py:9-28,41-77, backbones_2d/base_bev_backbone.py:232-262) and their autograd. */
+int rd_conv_bn_act_fwd(const float *in, int in_rows, int Cin, const void *weight, int w_format, int taps, const float *bias, float *raw,
+                       int out_rows, int Cout, const rd_conv_index *idx, float *stats, const float *gamma, const float *beta, float eps,
+                       float momentum, float *running_mean, float *running_var, const float *residual, int act, float *y, float *side,
+                       void *ev0, void *ev1, void *stream);
+int rd_conv_bn_act_bwd(const float *raw, const float *y, const float *grad_y, int out_rows, int Cout, const float *gamma, const float *side,
+                       int act, int has_residual, float *grad_raw, float *grad_res, float *grad_gamma_beta, const void *w_dgrad, int w_format,
+                       int taps, float *grad_in, int in_rows, int Cin, const rd_conv_index *bwd_idx, const float *in,
+                       const rd_conv_index *fwd_idx, float *grad_wk, void *ev_d0, void *ev_d1, void *ev_w0, void *ev_w1, void *main_stream,
+                       void *side_stream);
+
 /* Data gradient on the forward weights: grad_in[i][c] = sum_t sum_n grad_out[src_bwd(i,t)][n] * weight_k[n][t][c], with weight_k the
  * FORWARD kernel layout [Cout][taps][Cin] (the kernel reads it transposed; no re-laid-out copy) and idx the backward index
  * (transposed neighbour table / flip = 1 for sub-manifold, the transposed geometry for dense convolutions).  Cout % 32 == 0

@@ -817,15 +817,60 @@ def bn_act_train_tensors(x, gamma, beta, running_mean, running_var, eps, momentu
     return _BNActFn.apply(x, gamma, beta, None, running_mean, running_var, eps, momentum, act, stats, group)
 
 
+COMPOSITE = [os.environ.get("RD_COMPOSITE", "1") != "0"]          # A/B switch: one library call per layer and direction (composite.hip)
+
+
+def _side_handles(dev, param):
+    """(raw handle of the main stream, raw handle of the weight-gradient stream or None) for a composite backward call; queues the
+    end-of-backward join like param_grad_stream.  None for the side stream when it is off or `param` may be read on the main stream
+    before the join (_side_ok)."""
+    side = _wgrad_stream(dev)
+    if side is None or not _side_ok(param):
+        return K._stream(), None
+    st = _PG_STATE.get(dev)
+    if st is None or not _WGRAD_JOIN_QUEUED[0]:
+        main = torch.cuda.current_stream(dev)
+        st = _PG_STATE[dev] = (main, main.cuda_stream, side.cuda_stream)
+        _queue_wgrad_join(dev, main)
+    return st[1], st[2]
+
+
 class _ConvBNActFn(torch.autograd.Function):
     """conv (+bias) -> train-mode BatchNorm (statistics from the conv epilogue) -> (+residual) -> activation as ONE autograd node:
     the same four launches as _ConvFn + _BNActFn (forward: conv, BN apply; backward: BN reduce + apply, data gradient, weight
     gradient), but one Function.apply and one backward node per layer instead of two (~20 us of host time per layer and step).
-    group: SyncBatchNorm process group (one small all-reduce in the forward, one in the backward)."""
+    group: SyncBatchNorm process group (one small all-reduce in the forward, one in the backward).
+    Fast path (COMPOSITE): forward and backward are ONE library call each (rd_conv_bn_act_fwd / _bwd, csrc/composite.hip) -- the
+    same launches in the same order on the same streams; the per-launch path below remains for SyncBatchNorm, the debug checks, the
+    pre-split experiment and weights the fast path has no operand format for."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, spec, Cout, gamma, beta, residual, running_mean, running_var, eps, momentum, act, group=None):
         sync = group is not None
+        Cin = x.shape[1]
+        fmt = None
+        if COMPOSITE[0] and not sync and not _DEBUG and x.is_cuda and spec.fwd_ix.mode != 3 and K.BN_PROFILE is None:
+            if _b3_wsplit(Cin, Cout):
+                frag = K.wants_frag_weights(spec.fwd_ix, spec.in_rows, spec.out_rows, Cin, Cout, spec.taps)
+                fmt = 2 if frag else 1
+                wop = operand_weight_split(weight, Cout, Cin, spec.taps, spec.param_kind, frag=frag)
+            elif not _b3_presplit(Cin, Cout, spec.fwd_ix.mode):
+                fmt = 0
+                wop = kernel_weight(weight, Cout, Cin, spec.taps, spec.param_kind)
+        if fmt is not None:
+            note_param_use(weight, bias)
+            stats = zeros_stats(2 * Cout, x.device)
+            raw, y, side = K.conv_bn_act_fwd(x, wop, fmt, spec.taps, bias, spec.fwd_ix, spec.out_rows, Cout, stats, gamma, beta, eps, momentum,
+                                             running_mean, running_var, residual, act, nbr_keepalive=spec.fwd_nbr)
+            ctx.spec, ctx.Cout, ctx.Cin = spec, Cout, Cin
+            ctx.has_bias, ctx.bias_ref, ctx.bias_feeds_bn = bias is not None, bias, True
+            ctx.wk = wop if fmt == 0 else None
+            ctx.xs = None
+            ctx.fast = True
+            ctx.act, ctx.has_res, ctx.group, ctx.count = act, residual is not None, None, None
+            ctx.save_for_backward(x, weight, raw, y, gamma, side)
+            return y
+        ctx.fast = False
         ext = zeros_stats(2 * Cout + (1 if sync else 0), x.device)
         stats = ext[:2 * Cout] if sync else ext
         raw = _ConvFn.forward_impl(ctx, x, weight, bias, spec, Cout, stats)
@@ -841,9 +886,50 @@ class _ConvBNActFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, weight, raw, y, gamma, side = ctx.saved_tensors
-        sync = (_group_sum(ctx.group), ctx.count) if ctx.group is not None else None
-        graw, gres, gg, gb_bn = K.bn_bwd(raw, y, gy.contiguous(), gamma, side, ctx.act, ctx.has_res, sync=sync)
         n = ctx.needs_input_grad
+        spec, Cout, Cin = ctx.spec, ctx.Cout, ctx.Cin
+        fmt = None
+        if ctx.fast and COMPOSITE[0] and K.BN_PROFILE is None:
+            # the data-gradient operand the per-launch path would pick (_ConvFn.backward_impl)
+            if not n[0]:
+                fmt, wd = (1 if K.get_conv_math() == "bf16x3" else 0), None
+            elif ctx.wk is None and Cout % 32 == 0 and _b3_wsplit(Cout, Cin):
+                frag = K.wants_frag_weights(spec.bwd_ix, spec.out_rows, spec.in_rows, Cout, Cin, spec.taps)
+                fmt, wd = (2 if frag else 1), operand_weight_split(weight, Cout, Cin, spec.taps, spec.param_kind, dgrad=True, frag=frag)
+            elif ctx.wk is not None and Cout % 32 == 0 and K.get_conv_math() == "f32":
+                fmt, wd = 0, ctx.wk
+        if fmt is not None:
+            gyc = gy if gy.is_contiguous() else gy.contiguous()
+            main_raw, side_raw = _side_handles(x.device, weight) if n[1] else (K._stream(), None)
+            gx, gres, gg, gb_bn, gwk, graw = K.conv_bn_act_bwd(raw, y, gyc, gamma, side, ctx.act, ctx.has_res, wd, fmt, spec.taps, n[0], spec.in_rows,
+                                                               Cin, spec.bwd_ix, x, spec.fwd_ix, n[1], main_raw, side_raw,
+                                                               fwd_nbr=spec.fwd_nbr, bwd_nbr=spec.bwd_nbr)
+            gw = None
+            if n[1]:
+                if side_raw is not None:
+                    _PG_KEEP.append((x, graw))          # read by the side stream: held until the streams join
+                if spec.param_kind == 0:
+                    gw = gwk.reshape(weight.shape)
+                elif weight.is_leaf and _defer_layout_ok(weight):
+                    gw = defer_weight_layout(gwk, weight, Cout, Cin, spec.taps, 4 if spec.param_kind == 1 else 5)
+                else:          # rare: the re-layout follows the weight gradient on its stream
+                    kind = 4 if spec.param_kind == 1 else 5
+                    if side_raw is not None:
+                        main = _PG_STATE[x.device][0]
+                        _set_stream(_WGRAD_STREAMS[x.device])
+                        try:
+                            gw = K.weight_layout(gwk, Cout, Cin, spec.taps, kind, False, out_shape=tuple(weight.shape))
+                        finally:
+                            _set_stream(main)
+                    else:
+                        gw = K.weight_layout(gwk, Cout, Cin, spec.taps, kind, False, out_shape=tuple(weight.shape))
+            # the bias in front of a train-mode BatchNorm has the exact gradient zero (_ConvFn.backward_impl)
+            gb = zeros_accum(Cout, gyc.device) if (ctx.has_bias and n[2]) else None
+            return gx, gw, gb, None, None, gg, gb_bn, gres, None, None, None, None, None, None
+        sync = (_group_sum(ctx.group), ctx.count) if ctx.group is not None else None
+        if ctx.fast and ctx.wk is None:
+            ctx.wk = None
+        graw, gres, gg, gb_bn = K.bn_bwd(raw, y, gy.contiguous(), gamma, side, ctx.act, ctx.has_res, sync=sync)
         gx, gw, gb = _ConvFn.backward_impl(ctx, x, weight, graw, n[0], n[1], n[2])
         return gx, gw, gb, None, None, gg, gb_bn, gres, None, None, None, None, None, None
 

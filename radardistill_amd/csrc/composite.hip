@@ -1,0 +1,81 @@
+// Composite entry points: one C call per layer and direction for the training step's most frequent layer,
+//     convolution (+ bias) -> train-mode BatchNorm (statistics from the conv epilogue) -> (+ residual) -> activation.
+// Each is exactly the sequence of library calls the host made one by one (same kernels, same arguments, same order of launches,
+// same streams) -- what disappears is the host work between them: the step is 44 such layers, and per layer and direction the Python
+// wrappers, argument checks, stream switches and autograd-helper calls around 2 (forward) / 4 (backward) launches cost 40-80 us of
+// host time against 15.7 ms for a whole host-bound step (tools/diag/host_timers.py, round 3).
+//   forward : rd_conv_fwd[_split] (statistics in the epilogue)  ->  rd_bn_train_fwd
+//   backward: rd_bn_bwd (reduction + apply)  ->  data gradient (rd_conv_fwd_split on the [Cin][taps][Cout] operand, or rd_conv_dgrad)
+//             ->  fork to the weight-gradient stream  ->  rd_conv_wgrad there
+// Optional HIP events (bench.py's roofline hooks) are recorded around the convolution launches on the stream they go to.
+#include "common.hpp"
+
+using namespace rd;
+
+static int record(void *ev, void *stream) {
+    if (!ev) return RD_OK;
+    RD_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev), reinterpret_cast<hipStream_t>(stream)));
+    return RD_OK;
+}
+
+extern "C" int rd_conv_bn_act_fwd(const float *in, int in_rows, int Cin, const void *weight, int w_format, int taps, const float *bias,
+                                  float *raw, int out_rows, int Cout, const rd_conv_index *idx, float *stats, const float *gamma,
+                                  const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                                  const float *residual, int act, float *y, float *side, void *ev0, void *ev1, void *stream) {
+    RD_REQUIRE(raw && y && side && stats, "rd_conv_bn_act_fwd: raw, y, side (4 x Cout) and stats (2 x Cout, zero-filled) are required");
+    RD_REQUIRE(w_format >= 0 && w_format <= 2, "rd_conv_bn_act_fwd: weight format %d (0 fp32 kernel layout, 1 split, 2 fragment-major split)", w_format);
+    int rc = record(ev0, stream);
+    if (rc) return rc;
+    if (w_format == 0)
+        rc = rd_conv_fwd(in, in_rows, Cin, reinterpret_cast<const float *>(weight), taps, bias, raw, out_rows, Cout, idx, nullptr, nullptr, nullptr, 0,
+                         stats, stream);
+    else
+        rc = rd_conv_fwd_split(in, 0, in_rows, Cin, weight, w_format, taps, bias, raw, out_rows, Cout, idx, nullptr, nullptr, nullptr, 0, stats,
+                               stream);
+    if (rc) return rc;
+    rc = record(ev1, stream);
+    if (rc) return rc;
+    return rd_bn_train_fwd(raw, out_rows, Cout, stats, gamma, beta, eps, momentum, running_mean, running_var, residual, act, y, side,
+                           side + Cout, side + 2 * Cout, side + 3 * Cout, stream);
+}
+
+extern "C" int rd_conv_bn_act_bwd(const float *raw, const float *y, const float *grad_y, int out_rows, int Cout, const float *gamma,
+                                  const float *side, int act, int has_residual, float *grad_raw, float *grad_res, float *grad_gamma_beta,
+                                  const void *w_dgrad, int w_format, int taps, float *grad_in, int in_rows, int Cin,
+                                  const rd_conv_index *bwd_idx, const float *in, const rd_conv_index *fwd_idx, float *grad_wk,
+                                  void *ev_d0, void *ev_d1, void *ev_w0, void *ev_w1, void *main_stream, void *side_stream) {
+    RD_REQUIRE(raw && grad_y && side && grad_raw && grad_gamma_beta, "rd_conv_bn_act_bwd: raw, grad_y, side, grad_raw, grad_gamma_beta are required");
+    RD_REQUIRE(w_format >= 0 && w_format <= 2, "rd_conv_bn_act_bwd: weight format %d", w_format);
+    // BatchNorm (+ activation) backward: grad_gamma_beta = [grad_gamma | grad_beta], zero-filled by the caller
+    int rc = rd_bn_bwd(raw, y, grad_y, out_rows, Cout, gamma, side, side + Cout, side + 2 * Cout, side + 3 * Cout, act, has_residual, grad_raw,
+                       grad_res, grad_gamma_beta, grad_gamma_beta + Cout, main_stream);
+    if (rc) return rc;
+    if (grad_in) {          // data gradient: main stream (the next backward node consumes it)
+        RD_REQUIRE(w_dgrad && bwd_idx, "rd_conv_bn_act_bwd: the data gradient needs its weight operand and the backward index");
+        rc = record(ev_d0, main_stream);
+        if (rc) return rc;
+        if (w_format == 0)          // exact fp32: forward kernel layout [Cout][taps][Cin], read transposed
+            rc = rd_conv_dgrad(grad_raw, out_rows, Cout, reinterpret_cast<const float *>(w_dgrad), taps, grad_in, in_rows, Cin, bwd_idx, main_stream);
+        else                        // bf16x3: [Cin][taps][Cout] split operand, a forward convolution over the backward index
+            rc = rd_conv_fwd_split(grad_raw, 0, out_rows, Cout, w_dgrad, w_format, taps, nullptr, grad_in, in_rows, Cin, bwd_idx, nullptr, nullptr,
+                                   nullptr, 0, nullptr, main_stream);
+        if (rc) return rc;
+        rc = record(ev_d1, main_stream);
+        if (rc) return rc;
+    }
+    if (grad_wk) {          // weight gradient: feeds nobody until the optimizer -> side stream, after it has seen grad_raw
+        RD_REQUIRE(in && fwd_idx, "rd_conv_bn_act_bwd: the weight gradient needs the layer input and the forward index");
+        void *ws = side_stream ? side_stream : main_stream;
+        if (side_stream) {
+            rc = rd_stream_fork(main_stream, side_stream);
+            if (rc) return rc;
+        }
+        rc = record(ev_w0, ws);
+        if (rc) return rc;
+        rc = rd_conv_wgrad(in, in_rows, Cin, grad_raw, out_rows, Cout, taps, fwd_idx, grad_wk, ws);
+        if (rc) return rc;
+        rc = record(ev_w1, ws);
+        if (rc) return rc;
+    }
+    return RD_OK;
+}

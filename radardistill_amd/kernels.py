@@ -240,7 +240,17 @@ def prefill_event_pool(n):
 
 
 def timing_event():
-    return _EVENT_POOL.pop() if _EVENT_POOL else torch.cuda.Event(enable_timing=True)
+    if _EVENT_POOL:
+        return _EVENT_POOL.pop()
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()          # creates the HIP handle (the composite entry points record through the raw handle)
+    return e
+
+
+def _ev(e):
+    """Raw hipEvent_t of a torch event as an int (0 / None = no event)."""
+    h = e.cuda_event
+    return h if isinstance(h, int) else getattr(h, "value", None)
 
 
 # Optional per-launch timing hook used by bench.py for the roofline of the dominant kernel (k_conv_igemm<128,2,2,false>):
@@ -409,6 +419,122 @@ def conv_fwd(x, weight_k, taps, bias, out_rows, Cout, ix, scale=None, shift=None
     return out
 
 
+def _conv_flops_entry(ix, e0, e1, in_rows, out_rows, Cin, Cout, taps, tile, nbr_keepalive, mode_off=0):
+    """CONV_PROFILE record of one launch (see conv_fwd)."""
+    if ix.mode == 0:
+        pairs = getattr(nbr_keepalive, "_rd_pairs", None) if nbr_keepalive is not None else None
+        if pairs is None and nbr_keepalive is not None:
+            pairs = (nbr_keepalive >= 0).sum()
+            nbr_keepalive._rd_pairs = pairs
+        return (e0, e1, pairs, 2.0 * Cin * Cout, (in_rows, Cin, Cout, taps, mode_off + ix.mode, tile))
+    return (e0, e1, None, 2.0 * out_rows * taps * Cin * Cout, (in_rows, Cin, Cout, taps, mode_off + ix.mode, tile))
+
+
+def _conv_tag(ix, in_rows, out_rows, Cin, Cout, taps, w_format):
+    tile = 128 if ((out_rows + 127) // 128) * ((Cout + 127) // 128) >= 384 else 64
+    if taps == 1 and get_conv_math() == "bf16x3" and os.environ.get("RD_GEMM_TILE64", "1") != "0":
+        tile = 64
+    return _kernel_tag(ix, in_rows, out_rows, Cin, Cout, taps, False, tile, w_format)
+
+
+def conv_bn_act_fwd(x, weight, w_format, taps, bias, ix, out_rows, Cout, stats, gamma, beta, eps, momentum, running_mean, running_var,
+                    residual, act, nbr_keepalive=None):
+    """ONE library call (rd_conv_bn_act_fwd) for conv (+ bias) -> train-mode BatchNorm -> (+ residual) -> activation:
+    -> (raw conv output, y, side (4, Cout)).  weight: w_format 0 = fp32 kernel layout, 1 = split, 2 = fragment-major split.
+    stats: zero-filled (2 * Cout,) accumulator for the batch sums."""
+    _chk(x, f32, "conv input", 2)
+    in_rows, Cin = x.shape
+    if weight.numel() != Cout * taps * Cin:
+        raise RuntimeError(f"conv weight has {weight.numel()} elements, expected {Cout}*{taps}*{Cin}")
+    if ix.mode == 0 and nbr_keepalive is not None and (nbr_keepalive.shape != (out_rows, taps) or nbr_keepalive.dtype != i32):
+        raise RuntimeError(f"neighbour table shape {tuple(nbr_keepalive.shape)} != ({out_rows}, {taps})")
+    if stats.numel() != 2 * Cout or gamma.numel() != Cout or beta.numel() != Cout:
+        raise RuntimeError("conv_bn_act_fwd: stats / gamma / beta do not match Cout")
+    if residual is not None and (residual.shape != (out_rows, Cout) or not residual.is_contiguous() or residual.dtype != f32):
+        raise RuntimeError("conv_bn_act_fwd: residual must be a contiguous fp32 (out_rows, Cout) tensor")
+    if bias is not None and bias.numel() != Cout:
+        raise RuntimeError("conv_bn_act_fwd: bias size")
+    dev = x.device
+    raw = torch.empty((out_rows, Cout), dtype=f32, device=dev)
+    y = torch.empty((out_rows, Cout), dtype=f32, device=dev)
+    side = torch.empty((4, Cout), dtype=f32, device=dev)
+    e0 = e1 = None
+    if CONV_PROFILE is not None and (Cout > 64 or PROFILE_ALL) and ix.mode != 3:
+        tag = _conv_tag(ix, in_rows, out_rows, Cin, Cout, taps, w_format)
+        if PROFILE_TAGS is None or tag in PROFILE_TAGS:
+            e0, e1 = timing_event(), timing_event()
+    check(native.lib().rd_conv_bn_act_fwd(_p(x), in_rows, Cin, _p(weight), int(w_format), taps, _p(bias), _p(raw), out_rows, Cout, ix, _p(stats),
+                                          _p(gamma), _p(beta), eps, momentum, _p(running_mean), _p(running_var), _p(residual), act, _p(y),
+                                          _p(side), _ev(e0) if e0 is not None else None, _ev(e1) if e1 is not None else None, _stream()),
+          "rd_conv_bn_act_fwd")
+    if e0 is not None:
+        CONV_PROFILE.append(_conv_flops_entry(ix, e0, e1, in_rows, out_rows, Cin, Cout, taps, tag, nbr_keepalive))
+    return raw, y, side
+
+
+def conv_bn_act_bwd(raw, y, grad_y, gamma, side, act, has_res, w_dgrad, w_format, taps, want_gx, in_rows, Cin, bwd_ix, x, fwd_ix, want_gw,
+                    main_raw, side_raw, fwd_nbr=None, bwd_nbr=None):
+    """ONE library call (rd_conv_bn_act_bwd): BatchNorm (+ act) backward, data gradient on the main stream, weight gradient on the
+    side stream (side_raw None: main stream).  -> (grad_in or None, grad_residual or None, grad_gamma, grad_beta, grad_wk kernel layout or None)."""
+    _chk(raw, f32, "raw", 2); _chk(grad_y, f32, "grad_y", 2)
+    out_rows, Cout = raw.shape
+    if grad_y.shape != raw.shape or (y is not None and y.shape != raw.shape) or side.shape != (4, Cout):
+        raise RuntimeError("conv_bn_act_bwd: shape mismatch")
+    if want_gx and w_dgrad.numel() != Cout * taps * Cin:
+        raise RuntimeError("conv_bn_act_bwd: data-gradient weight operand size")
+    if want_gw and (x.shape != (in_rows, Cin) or not x.is_contiguous()):
+        raise RuntimeError("conv_bn_act_bwd: layer input shape")
+    from . import autograd as _A
+    dev = raw.device
+    graw = torch.empty_like(raw)
+    gres = torch.empty_like(raw) if has_res else None
+    g2 = _A.zeros_accum(2 * Cout, dev)
+    gx = torch.empty((in_rows, Cin), dtype=f32, device=dev) if want_gx else None
+    gwk = _A.zeros_accum(Cout * taps * Cin, dev).view(Cout, taps, Cin) if want_gw else None
+    if act == 1 and not has_res:
+        y = None
+    d0 = d1 = w0 = w1 = None
+    if CONV_PROFILE is not None and want_gx and (Cin > 64 or PROFILE_ALL):
+        dtag = _conv_tag(bwd_ix, out_rows, in_rows, Cout, Cin, taps, w_format) if w_format else (128 if ((in_rows + 127) // 128) * ((Cin + 127) // 128) >= 384 else 64)
+        if PROFILE_TAGS is None or dtag in PROFILE_TAGS:
+            d0, d1 = timing_event(), timing_event()
+    if WGRAD_PROFILE is not None and want_gw:
+        wtag = wgrad_tag(fwd_ix, in_rows, out_rows, Cin, Cout, taps)
+        if PROFILE_TAGS is None or wtag in PROFILE_TAGS:
+            w0, w1 = timing_event(), timing_event()
+    check(native.lib().rd_conv_bn_act_bwd(_p(raw), _p(y), _p(grad_y), out_rows, Cout, _p(gamma), _p(side), act, int(has_res), _p(graw), _p(gres),
+                                          _p(g2), _p(w_dgrad) if want_gx else None, int(w_format), taps, _p(gx), in_rows, Cin, bwd_ix,
+                                          _p(x) if want_gw else None, fwd_ix, _p(gwk),
+                                          _ev(d0) if d0 is not None else None, _ev(d1) if d1 is not None else None,
+                                          _ev(w0) if w0 is not None else None, _ev(w1) if w1 is not None else None, main_raw, side_raw),
+          "rd_conv_bn_act_bwd")
+    if d0 is not None:
+        CONV_PROFILE.append(_conv_flops_entry(bwd_ix, d0, d1, out_rows, in_rows, Cout, Cin, taps, dtag, bwd_nbr, mode_off=0 if w_format else 10))
+    if w0 is not None:
+        pairs = None
+        if fwd_ix.mode == 0 and fwd_nbr is not None:
+            pairs = getattr(fwd_nbr, "_rd_pairs", None)
+            if pairs is None:
+                pairs = (fwd_nbr >= 0).sum()
+                fwd_nbr._rd_pairs = pairs
+        WGRAD_PROFILE.append((w0, w1, pairs, 2.0 * Cin * Cout if pairs is not None else 2.0 * out_rows * taps * Cin * Cout,
+                              (in_rows, Cin, Cout, taps, fwd_ix.mode, wtag)))
+    return gx, gres, g2[:Cout], g2[Cout:], gwk, graw
+
+
+def wgrad_tag(ix, in_rows, out_rows, Cin, Cout, taps, in_split=False, go_split=False):
+    """Which instantiation conv_wgrad_impl (conv.hip) launches: the Cin tile is 128 for Cin >= 128 in bf16x3 mode; in exact fp32 only when
+    that leaves >= 32 (tap, tile) pairs; dense stride-1 3x3 layers take the halo-staged kernel."""
+    b3 = get_conv_math() == "bf16x3" and Cout >= 64 and Cin >= 64
+    wide = Cin >= 128 if b3 else (Cin >= 128 and Cout >= 64 and taps * ((Cout + 127) // 128) * ((Cin + 127) // 128) >= 32)
+    tag = ("wgrad_b3_" if b3 else "wgrad_f32_") + ("deform_" if ix.mode == 3 else "") + ("128" if wide else "64")
+    if (get_conv_math() == "bf16x3" and ix.mode == 1 and taps == 9 and ix.KH == 3 and ix.KW == 3 and ix.stride == 1 and ix.pad == 1
+            and ix.Hin == ix.Hout and ix.Win == ix.Wout and not in_split and not go_split and Cin % 4 == 0 and Cout % 4 == 0 and Cin >= 32
+            and Cout >= 32 and in_rows == out_rows and os.environ.get("RD_WGRAD_D3", "1") != "0"):
+        tag = "wgrad_d3"
+    return tag
+
+
 def conv_dgrad(grad_out, weight_k, taps, in_rows, Cin, ix_bwd, nbr_keepalive=None):
     """grad_out (out_rows, Cout), weight_k the FORWARD kernel layout (Cout, taps, Cin) -> grad_in (in_rows, Cin)."""
     _chk(grad_out, f32, "dgrad grad_out", 2)
@@ -454,15 +580,7 @@ def conv_wgrad(x, grad_out, taps, ix, nbr_keepalive=None, in_split=False, go_spl
     gw = _A.zeros_accum(Cout * taps * Cin, x.device).view(Cout, taps, Cin)          # zero-initialised accumulator (atomics)
     prof = WGRAD_PROFILE is not None
     if prof:
-        # which instantiation conv_wgrad_impl (conv.hip) launches: the Cin tile is 128 for Cin >= 128 in bf16x3 mode; in exact fp32
-        # only when that leaves >= 32 (tap, tile) pairs
-        b3 = get_conv_math() == "bf16x3" and Cout >= 64 and Cin >= 64
-        wide = Cin >= 128 if b3 else (Cin >= 128 and Cout >= 64 and taps * ((Cout + 127) // 128) * ((Cin + 127) // 128) >= 32)
-        tag = ("wgrad_b3_" if b3 else "wgrad_f32_") + ("deform_" if ix.mode == 3 else "") + ("128" if wide else "64")
-        if (get_conv_math() == "bf16x3" and ix.mode == 1 and taps == 9 and ix.KH == 3 and ix.KW == 3 and ix.stride == 1 and ix.pad == 1
-                and ix.Hin == ix.Hout and ix.Win == ix.Wout and not in_split and not go_split and Cin % 4 == 0 and Cout % 4 == 0 and Cin >= 32
-                and Cout >= 32 and in_rows == out_rows and os.environ.get("RD_WGRAD_D3", "1") != "0"):
-            tag = "wgrad_d3"
+        tag = wgrad_tag(ix, in_rows, out_rows, Cin, Cout, taps, in_split, go_split)
         prof = PROFILE_TAGS is None or tag in PROFILE_TAGS
     if prof:
         e0 = timing_event(); e1 = timing_event()

@@ -77,6 +77,10 @@ SIGNATURES = {
     "rd_vfe_seg_stats": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, _P, _P]),
     "rd_vfe_seg_max": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
     "rd_conv_fwd": (c_int, [_P, c_int, c_int, _P, c_int, _P, _P, c_int, c_int, ctypes.POINTER(ConvIndex), _P, _P, _P, c_int, _P, _P]),
+    "rd_conv_bn_act_fwd": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, _P, c_int, c_int, ctypes.POINTER(ConvIndex), _P, _P, _P, c_f32, c_f32, _P, _P,
+                                   _P, c_int, _P, _P, _P, _P, _P]),
+    "rd_conv_bn_act_bwd": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, c_int, c_int,
+                                   ctypes.POINTER(ConvIndex), _P, ctypes.POINTER(ConvIndex), _P, _P, _P, _P, _P, _P, _P]),
     "rd_set_conv_math": (c_int, [c_int]),
     "rd_get_conv_math": (c_int, []),
     "rd_split_bf16": (c_int, [_P, c_i64, _P, _P]),
