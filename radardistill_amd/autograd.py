@@ -113,6 +113,16 @@ _BN_TOUCHED = []          # BatchNorm modules that ran in train mode this step (
 
 
 def begin_step(device):
+    # The arenas are recycled here: whatever the weight-gradient stream still has in flight (a backward pass whose end-of-pass join never
+    # ran -- an exception inside backward, a pass abandoned by its caller -- or callers that never pass through a join) must be done
+    # before the old accumulators are freed and their memory is zero-filled again.  One event record + wait per step.
+    if device.type == "cuda" and _WGRAD_STREAMS:
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        for d, side in _WGRAD_STREAMS.items():
+            if d.index == idx:
+                torch.cuda.current_stream(d).wait_stream(side)
+        if _PG_KEEP and not _WGRAD_JOIN_QUEUED[0]:
+            _PG_KEEP.clear()
     ARENA.begin_step(device)
     GRAD_ARENA.begin_step(device)
     if device.type == "cuda":
@@ -376,8 +386,8 @@ def _side_ok(param):
     the main stream.  A non-leaf weight (the concatenated CenterHead branches) names its leaves in `_rd_leaves`."""
     if param is None:
         return True
-    if _PARAM_USES.get(id(param), 0) > 1:
-        return False
+    if _PARAM_USES.get(id(param), 0) > 1 or getattr(param, "_backward_hooks", None):
+        return False          # (a tensor hook reads the gradient on the main stream the moment backward returns it)
     leaves = getattr(param, "_rd_leaves", None)
     if leaves is not None:
         return (not param.is_leaf or param.grad is None) and all(p.grad is None for p in leaves)
