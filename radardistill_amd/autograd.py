@@ -827,7 +827,10 @@ def bn_act_train_tensors(x, gamma, beta, running_mean, running_var, eps, momentu
     return _BNActFn.apply(x, gamma, beta, None, running_mean, running_var, eps, momentum, act, stats, group)
 
 
-COMPOSITE = [os.environ.get("RD_COMPOSITE", "1") != "0"]          # A/B switch: one library call per layer and direction (composite.hip)
+# One library call per layer and direction (composite.hip).  OFF by default: measured neutral to slightly negative (round 3, host-bound
+# B = 2 step 15.6 ms per-launch vs 15.9 ms composite; B = 8 18.5 vs 18.6) -- the four C calls it merges cost ~4 us each, while the
+# host time of a layer is torch's own: tensor allocations, Function.apply, saved tensors, the engine's node bookkeeping.
+COMPOSITE = [os.environ.get("RD_COMPOSITE", "0") == "1"]
 
 
 def _side_handles(dev, param):

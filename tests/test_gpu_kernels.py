@@ -76,6 +76,46 @@ def test_fused_conv_bn_act_node_equals_separate_nodes(act, res):
         close(a, b, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+def test_composite_layer_calls_equal_the_per_launch_path(math):
+    """rd_conv_bn_act_fwd / rd_conv_bn_act_bwd (one library call per layer and direction, autograd.COMPOSITE) issue exactly the
+    launches of the per-launch path: with the reductions in fixed order every output, running statistic and gradient is bit-identical,
+    for a sparse layer with a residual and a dense 3x3 layer, weight gradient on the side stream."""
+    A, K, SP = _mods()
+    rng = np.random.default_rng(5)
+    B, H, W, C = 2, 24, 32, 64
+    x = torch.from_numpy(rng.normal(size=(B * H * W, C)).astype(np.float32)).to(DEV)
+    res = torch.from_numpy(rng.normal(size=(B * H * W, C)).astype(np.float32)).to(DEV)
+    w = torch.from_numpy((rng.normal(size=(C, C, 3, 3)) / 24).astype(np.float32))
+    go = torch.from_numpy(rng.normal(size=(B * H * W, C)).astype(np.float32)).to(DEV)
+    K.set_conv_math(math)
+    K.set_deterministic(True)
+    prev = A.COMPOSITE[0]
+    try:
+        out = {}
+        for comp in (False, True):
+            A.COMPOSITE[0] = comp
+            conv = torch.nn.Conv2d(C, C, 3, padding=1, bias=True).to(DEV)
+            bn = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01).to(DEV).train()
+            with torch.no_grad():
+                conv.weight.copy_(w); conv.bias.fill_(0.25); bn.weight.fill_(1.5); bn.bias.fill_(-0.1)
+            xd, rd = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+            A.begin_step(torch.device(DEV))
+            spec = A.dense_conv_spec(B, H, W, 3, 3, 1, 1)
+            y1 = A.conv_bn_act_train(xd, conv.weight, conv.bias, spec, C, bn, residual=rd, act=1)
+            y2 = A.conv_bn_act_train(y1, conv.weight, conv.bias, spec, C, bn, residual=None, act=1)          # the weight is used twice
+            (y2 * go).sum().backward()
+            torch.cuda.synchronize()
+            out[comp] = [t.detach().clone() for t in (y1, y2, xd.grad, rd.grad, conv.weight.grad, conv.bias.grad, bn.weight.grad, bn.bias.grad,
+                                                      bn.running_mean, bn.running_var)]
+        for a, b in zip(out[False], out[True]):
+            assert torch.equal(a, b)
+    finally:
+        A.COMPOSITE[0] = prev
+        K.set_deterministic(False)
+        K.set_conv_math("f32")
+
+
 @pytest.mark.parametrize("xmajor", [False, True])
 def test_rankgrid_downsample_from_grid_equals_from_coords(xmajor):
     """rd_rankgrid_downsample_grid (marks the SparseConv2d(k3, s2, p1) output set from the input rank GRID, no host-side row count)
