@@ -360,6 +360,64 @@ def g8_optim():
     save("g8_optim.npz", **out)
 
 
+def g10_augment():
+    """The `_distill` world transforms, the augmentor's tail and the nuScenes sweep assembly, produced by the reference's own functions
+    (pcdet/datasets/augmentor/augmentor_utils.py:28-180, data_augmentor.py:239-262,396-425, nuscenes/nuscenes_dataset_distill.py:82-117,
+    240-283) under seeded global numpy generators.  common_utils is the reference's real file here (rotate_points_along_z,
+    limit_period); box_utils and the dataset base classes stay inert placeholders (not called by these paths)."""
+    import tempfile
+    import types
+    from pathlib import Path
+    from tests.golden import augment_case as AC
+    L.install()
+    del sys.modules["pcdet.utils.common_utils"]                      # the loader's reduced stand-in -> the real module
+    L._ns("pcdet.datasets", f"{L.REF_ROOT}/pcdet/datasets")
+    L._ns("pcdet.datasets.augmentor", f"{L.REF_ROOT}/pcdet/datasets/augmentor")
+    L._ns("pcdet.datasets.nuscenes", f"{L.REF_ROOT}/pcdet/datasets/nuscenes")
+    L._ns("pcdet.ops.roiaware_pool3d", f"{L.REF_ROOT}/pcdet/ops/roiaware_pool3d")
+    L._stub("pcdet.ops.roiaware_pool3d.roiaware_pool3d_utils")
+    L._stub("pcdet.datasets.dataset_distill", DatasetTemplate_Distill=object)
+    L._stub("pcdet.datasets.nuscenes.nuscenes_dataset", NuScenesDataset=object)
+    L._stub("pyquaternion", Quaternion=None)
+    L._stub("pcdet.utils.spconv_utils", spconv=None)                # common_utils imports it for an unrelated helper
+    L._stub("nuscenes"); L._stub("nuscenes.utils"); L._stub("nuscenes.utils.data_classes", RadarPointCloud=None)
+    CU = L.load("pcdet.utils.common_utils")
+    AU = L.load("pcdet.datasets.augmentor.augmentor_utils")
+    for n in ("database_sampler", "database_sampler_distill", "database_sampler_radar"):
+        L._stub("pcdet.datasets.augmentor." + n)
+    DA = L.load("pcdet.datasets.augmentor.data_augmentor").DataAugmentor
+    out = {}
+    for seed in AC.SEEDS:
+        b, p, r = AC.scene(seed)
+        np.random.seed(seed)
+        for axis in ("x", "y"):
+            b, p, r, en = getattr(AU, "random_flip_distill_along_%s" % axis)(b, p, r, return_flip=True)
+            out[f"flip_{axis}_{seed}"] = np.array(bool(en))
+        b, p, r, rot = AU.global_rotation_distill(b, p, r, rot_range=AC.ROT_RANGE, return_rot=True)
+        b, p, r, sc = AU.global_scaling_distill(b, p, r, AC.SCALE_RANGE, return_scale=True)
+        d = DA.random_world_translation_distill(None, {"gt_boxes": b, "points": p, "radar_points": r}, {"NOISE_TRANSLATE_STD": AC.TRANSLATE_STD})
+        # the augmentor's tail (forward :407-425) on an empty queue: heading wrapped, class mask applied
+        shell = types.SimpleNamespace(data_augmentor_queue=[])
+        mask = np.arange(len(b)) % 3 != 1
+        d.update(gt_names=np.array(["car", "bus", "truck"] * 3)[:len(b)], gt_boxes_mask=mask)
+        d["gt_boxes"][:, 6] += 3.0 * (seed - 3)                     # headings far outside [-pi, pi)
+        d = DA.forward(shell, d)
+        out[f"rot_{seed}"], out[f"scale_{seed}"], out[f"translate_{seed}"] = np.array(rot), np.array(sc), d["noise_translate"]
+        out[f"boxes_{seed}"], out[f"points_{seed}"], out[f"radar_{seed}"] = d["gt_boxes"], d["points"], d["radar_points"]
+    ND = L.load("pcdet.datasets.nuscenes.nuscenes_dataset_distill").NuScenesDataset_Distill
+    with tempfile.TemporaryDirectory() as tmp:
+        info = AC.write_sample_files(os.path.join(tmp, "data"), seed=0)
+        fake = types.SimpleNamespace(infos=[info], root_path=Path(tmp) / "data" / "v")          # the reference reads root_path.parent / path
+        fake.get_sweep = types.MethodType(ND.get_sweep, fake)
+        fake._load_points = lambda path: np.fromfile(os.path.join(tmp, "data", path), dtype=np.float32)
+        np.random.seed(5)
+        out["lidar_sweeps"] = ND.get_lidar_with_sweeps(fake, 0, max_sweeps=10)
+        out["radar_sweeps"] = ND.get_radar_with_sweeps(fake, 0, max_sweeps=6)
+        sw, tl = ND.get_sweep(fake, info["sweeps"][3])
+        out["sweep3_points"], out["sweep3_times"] = sw, tl
+    save("g10_augment.npz", **out)
+
+
 def _fresh_reference_modules():
     """Every set starts from a clean slate: leaf files of the reference (and the placeholders / bridges an earlier set installed for
     them, e.g. g4's reduced iou3d_nms_utils) are dropped from sys.modules so the next set imports what IT needs."""
@@ -369,9 +427,9 @@ def _fresh_reference_modules():
 
 if __name__ == "__main__":
     torch.set_grad_enabled(False)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     fns = {"g1": g1_vfe, "g2": g2_dense_enc, "g3": g3_radar_distill, "g4": g4_center_head, "g5": g5_conv5, "g6": g6_decode, "g7": g7_pillar,
-           "g8": g8_optim, "g9": g9_pillar_train}
+           "g8": g8_optim, "g9": g9_pillar_train, "g10": g10_augment}
     for w in which:
         _fresh_reference_modules()
         torch.set_grad_enabled(False)
