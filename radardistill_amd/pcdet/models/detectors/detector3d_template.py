@@ -149,97 +149,70 @@ class Detector3DTemplate(nn.Module):
     def forward(self, **kwargs):
         raise NotImplementedError
 
-    # ---- checkpoints (detector3d_template.py:411-496)
+    # ---- recall records and checkpoints: the logic lives in radardistill_amd/checkpoint.py; these are the reference's entry points
     @staticmethod
     def generate_recall_record(box_preds, recall_dict, batch_index, data_dict=None, thresh_list=None):
-        """detector3d_template.py:367-409: how many ground-truth boxes have a prediction above each 3-D IoU threshold (the pairwise
-        IoU runs on the HIP overlap kernel; one host read per threshold, as in the reference)."""
+        """detector3d_template.py:367-409 -- `recall_dict` counts, per 3-D IoU threshold, the ground-truth boxes that some prediction
+        (`rcnn_<t>`) / some first-stage proposal (`roi_<t>`, only when the batch carries `rois`) overlaps by more than the threshold,
+        and the ground-truth boxes seen (`gt`).  Pairwise IoU on the HIP overlap kernel."""
+        from .... import checkpoint as CK
         from ...ops.iou3d_nms import iou3d_nms_utils
         if 'gt_boxes' not in data_dict:
             return recall_dict
-        rois = data_dict['rois'][batch_index] if 'rois' in data_dict else None
-        gt_boxes = data_dict['gt_boxes'][batch_index]
-        if recall_dict.__len__() == 0:
+        if not recall_dict:
             recall_dict = {'gt': 0}
-            for cur_thresh in thresh_list:
-                recall_dict['roi_%s' % (str(cur_thresh))] = 0
-                recall_dict['rcnn_%s' % (str(cur_thresh))] = 0
-        cur_gt = gt_boxes
-        nonzero = (cur_gt.sum(dim=1) != 0).nonzero()
-        k = int(nonzero.max().item()) if nonzero.numel() else -1          # trailing all-zero rows are padding
-        cur_gt = cur_gt[:k + 1]
-        if cur_gt.shape[0] > 0:
-            if box_preds.shape[0] > 0:
-                iou3d_rcnn = iou3d_nms_utils.boxes_iou3d_gpu(box_preds[:, 0:7], cur_gt[:, 0:7])
-            else:
-                iou3d_rcnn = torch.zeros((0, cur_gt.shape[0]))
-            if rois is not None:
-                iou3d_roi = iou3d_nms_utils.boxes_iou3d_gpu(rois[:, 0:7], cur_gt[:, 0:7])
-            for cur_thresh in thresh_list:
-                if iou3d_rcnn.shape[0] > 0:
-                    recall_dict['rcnn_%s' % str(cur_thresh)] += (iou3d_rcnn.max(dim=0)[0] > cur_thresh).sum().item()
-                if rois is not None:
-                    recall_dict['roi_%s' % str(cur_thresh)] += (iou3d_roi.max(dim=0)[0] > cur_thresh).sum().item()
-            recall_dict['gt'] += cur_gt.shape[0]
+            for t in thresh_list:
+                recall_dict[f'roi_{t}'] = 0
+                recall_dict[f'rcnn_{t}'] = 0
+        gt = CK.strip_padding(data_dict['gt_boxes'][batch_index])
+        if gt.shape[0] == 0:
+            return recall_dict
+        sources = {'rcnn': box_preds}
+        if 'rois' in data_dict:
+            sources['roi'] = data_dict['rois'][batch_index]
+        for tag, boxes in sources.items():
+            if boxes.shape[0] > 0:
+                hits = CK.count_recalled(iou3d_nms_utils.boxes_iou3d_gpu(boxes[:, 0:7], gt[:, 0:7]), thresh_list)
+                for t, n in zip(thresh_list, hits):
+                    recall_dict[f'{tag}_{t}'] += n
+        recall_dict['gt'] += gt.shape[0]
         return recall_dict
 
     def _load_state_dict(self, model_state_disk, *, strict=True):
-        state_dict = self.state_dict()
-        spconv_keys = find_all_spconv_keys(self)
-        update_model_state = {}
-        for key, val in model_state_disk.items():
-            if key in spconv_keys and key in state_dict and state_dict[key].shape != val.shape:
-                # spconv 1.x stored (k1, k2, c_in, c_out); 2.x / this build store (c_out, k1, k2, c_in)
-                val_native = val.transpose(-1, -2)
-                if val_native.shape == state_dict[key].shape:
-                    val = val_native.contiguous()
-                elif val.dim() == 4:
-                    val_implicit = val.permute(3, 0, 1, 2)
-                    if val_implicit.shape == state_dict[key].shape:
-                        val = val_implicit.contiguous()
-            if key in state_dict and state_dict[key].shape == val.shape:
-                update_model_state[key] = val
+        """-> (the model's state dict after loading, the entries taken from disk).  strict: exactly the fitted entries must make up the
+        whole model (torch raises otherwise); non-strict: entries that do not fit keep the model's current values."""
+        from .... import checkpoint as CK
+        own, fitted = CK.fit_state_to_model(self, model_state_disk, find_all_spconv_keys(self))
         if strict:
-            self.load_state_dict(update_model_state)
+            self.load_state_dict(fitted)
         else:
-            state_dict.update(update_model_state)
-            self.load_state_dict(state_dict)
-        return state_dict, update_model_state
+            own.update(fitted)
+            self.load_state_dict(own)
+        return own, fitted
 
     def load_params_from_file(self, filename, logger, to_cpu=False, pre_trained_path=None):
-        if not os.path.isfile(filename):
-            raise FileNotFoundError
+        from .... import checkpoint as CK
+        checkpoint = CK.read_checkpoint(filename, to_cpu)
         logger.info('==> Loading parameters from checkpoint %s to %s' % (filename, 'CPU' if to_cpu else 'GPU'))
-        loc_type = torch.device('cpu') if to_cpu else None
-        checkpoint = torch.load(filename, map_location=loc_type, weights_only=True)
-        model_state_disk = checkpoint['model_state']
-        if pre_trained_path is not None:
-            model_state_disk.update(torch.load(pre_trained_path, map_location=loc_type, weights_only=True)['model_state'])
-        version = checkpoint.get("version", None)
-        if version is not None:
-            logger.info('==> Checkpoint trained from version: %s' % version)
-        state_dict, update_model_state = self._load_state_dict(model_state_disk, strict=False)
-        for key in state_dict:
-            if key not in update_model_state:
-                logger.info('Not updated weight %s: %s' % (key, str(state_dict[key].shape)))
-        logger.info('==> Done (loaded %d/%d)' % (len(update_model_state), len(state_dict)))
+        disk = checkpoint['model_state']
+        if pre_trained_path is not None:          # a second file overlays the first (detector3d_template.py:449-452)
+            disk.update(CK.read_checkpoint(pre_trained_path, to_cpu)['model_state'])
+        if checkpoint.get('version', None) is not None:
+            logger.info('==> Checkpoint trained from version: %s' % checkpoint['version'])
+        own, fitted = self._load_state_dict(disk, strict=False)
+        for key in (k for k in own if k not in fitted):
+            logger.info('Not updated weight %s: %s' % (key, str(own[key].shape)))
+        logger.info('==> Done (loaded %d/%d)' % (len(fitted), len(own)))
 
     def load_params_with_optimizer(self, filename, to_cpu=False, optimizer=None, logger=None):
-        if not os.path.isfile(filename):
-            raise FileNotFoundError
-        loc_type = torch.device('cpu') if to_cpu else None
-        checkpoint = torch.load(filename, map_location=loc_type, weights_only=True)
-        epoch = checkpoint.get('epoch', -1)
-        it = checkpoint.get('it', 0.0)
+        """-> (it, epoch).  The optimizer state comes from the checkpoint or, failing that, from its `_optim` side file."""
+        from .... import checkpoint as CK
+        checkpoint = CK.read_checkpoint(filename, to_cpu)
         self._load_state_dict(checkpoint['model_state'], strict=True)
         if optimizer is not None:
-            if checkpoint.get('optimizer_state', None) is not None:
-                optimizer.load_state_dict(checkpoint['optimizer_state'])
-            else:
-                # the moments may sit next to the checkpoint as `<name>_optim.<ext>` (detector3d_template.py:484-490)
-                assert filename[-4] == '.', filename
-                optimizer_filename = '%s_optim.%s' % (filename[:-4], filename[-3:])
-                if os.path.exists(optimizer_filename):
-                    optimizer_ckpt = torch.load(optimizer_filename, map_location=loc_type, weights_only=True)
-                    optimizer.load_state_dict(optimizer_ckpt['optimizer_state'])
-        return it, epoch
+            opt_state = checkpoint.get('optimizer_state', None)
+            if opt_state is None and os.path.exists(CK.optimizer_side_file(filename)):
+                opt_state = CK.read_checkpoint(CK.optimizer_side_file(filename), to_cpu)['optimizer_state']
+            if opt_state is not None:
+                optimizer.load_state_dict(opt_state)
+        return checkpoint.get('it', 0.0), checkpoint.get('epoch', -1)

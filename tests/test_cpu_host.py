@@ -320,3 +320,32 @@ def test_config_set_overrides_and_logging():
     log_config_to_file(c, logger=lg)
     assert lg.lines[0] == "----------- A -----------" and "cfg.A.LR: 0.01" in lg.lines and "cfg.A.SUB.X: 7" in lg.lines and "cfg.FLAG: False" in lg.lines
     assert "----------- SUB -----------" in lg.lines
+
+
+def test_checkpoint_helpers_recall_counts_and_layout_fixups(tmp_path):
+    """radardistill_amd/checkpoint.py: recall counting for all thresholds at once, trailing zero padding of gt_boxes, the `_optim` side
+    file name, legacy sparse-kernel layouts (spconv 1.x (k, k, c_in, c_out) and its transposed variant) and name + shape fitting."""
+    from radardistill_amd import checkpoint as CK
+    iou = torch.tensor([[0.9, 0.2, 0.0], [0.4, 0.6, 0.0]])
+    assert CK.count_recalled(iou, [0.3, 0.5, 0.7]) == [2, 2, 1] and CK.count_recalled(iou[:0], [0.3]) == [0]
+    gt = torch.tensor([[1.0, 2, 3], [0, 0, 0], [4, 5, 6], [0, 0, 0], [0, 0, 0]])
+    assert CK.strip_padding(gt).shape[0] == 3 and CK.strip_padding(gt[3:]).shape[0] == 0
+    assert CK.optimizer_side_file("/a/b/checkpoint_epoch_3.pth") == "/a/b/checkpoint_epoch_3_optim.pth"
+    with pytest.raises(ValueError):
+        CK.optimizer_side_file("/a/b/ckpt.pt")
+    with pytest.raises(FileNotFoundError):
+        CK.read_checkpoint(str(tmp_path / "missing.pth"))
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.sp = torch.nn.Parameter(torch.zeros(8, 3, 3, 4))          # this build's sparse layout (c_out, k, k, c_in)
+            self.lin = torch.nn.Linear(4, 2)
+    net = Net()
+    v1 = torch.arange(8 * 3 * 3 * 4, dtype=torch.float32).view(3, 3, 4, 8)          # spconv 1.x
+    _, fitted = CK.fit_state_to_model(net, {"sp": v1, "lin.weight": torch.ones(2, 4), "lin.bias": torch.ones(3), "other": torch.ones(1)}, {"sp"})
+    assert set(fitted) == {"sp", "lin.weight"} and torch.equal(fitted["sp"], v1.permute(3, 0, 1, 2))
+    _, fitted = CK.fit_state_to_model(net, {"sp": torch.zeros(8, 3, 4, 3)}, {"sp"})          # last two axes swapped
+    assert tuple(fitted["sp"].shape) == (8, 3, 3, 4)
+    _, fitted = CK.fit_state_to_model(net, {"sp": v1}, set())          # not a sparse kernel: no re-layout is tried
+    assert "sp" not in fitted
