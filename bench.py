@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-bn", action="store_true", help="the reference's --sync_bn (tools/train.py:34,144-145): synchronised BatchNorm "
                     "statistics over the ranks (off in the headline, as in the reference's default)")
+    ap.add_argument("--amp-steps", type=int, default=-1, help="steps timed under the reference's --use_amp arithmetic (train.autocast: bf16 "
+                    "products, fp32 accumulate + AmpScaler loss scaling) after the other legs, reported as 'amp' BESIDE the fp32-class "
+                    "headline (-1 = the same count as --steps, 0 = skip)")
     ap.add_argument("--math", choices=["f32", "bf16x3"], default="bf16x3",
                     help="arithmetic of the implicit-GEMM conv kernels: bf16x3 = fp32 operands split into bf16 hi+lo, three bf16 MFMAs per "
                          "product, fp32 accumulate (~4e-6 relative error, inside the 1e-3 parity bound; parity-tested in "
@@ -313,6 +316,8 @@ def main():
     args = parse()
     if args.other_math_steps < 0:
         args.other_math_steps = args.steps
+    if args.amp_steps < 0:
+        args.amp_steps = args.steps
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -500,6 +505,38 @@ def main():
         K.set_conv_math(args.math)
         other = {"conv_math": om, "value": round(args.batch * world * args.other_math_steps / odt, 3), "unit": "samples/sec",
                  "ms_per_step": round(odt / args.other_math_steps * 1e3, 3), "steps": args.other_math_steps}
+    # the reference's `--use_amp` iteration (tools/train_utils/train_utils.py:57-64): autocast arithmetic (bf16 products, fp32 accumulate;
+    # train.autocast covers forward AND backward) + dynamic loss scaling, same barrier / max-over-ranks bracket.  Reported beside the headline.
+    amp = None
+    if args.amp_steps > 0:
+        from radardistill_amd.train import AmpScaler, autocast
+        scaler = AmpScaler(device)
+        it0 = args.warmup + args.steps + 3 + args.other_math_steps
+
+        def amp_step(it):
+            sched.step(it)
+            optimizer.zero_grad()
+            with autocast(True):
+                loss_, _, _ = model_func(run_model, dict(batches[it % len(batches)]))
+                scaler.scale(loss_).backward()
+            scaler.step(optimizer)
+            scaler.update()
+            return loss_
+
+        prev_math = K.get_conv_math()
+        amp_step(it0)
+        barrier()
+        t2 = time.perf_counter()
+        for it in range(it0 + 1, it0 + 1 + args.amp_steps):
+            amp_loss = amp_step(it)
+        barrier()
+        adt = D.max_over_ranks(time.perf_counter() - t2, device)
+        K.set_conv_math(prev_math)
+        amp = {"arithmetic": "train.autocast: MFMA products of bf16-rounded operands (1 of bf16x3's 3 terms), fp32 accumulate, fp32 storage and "
+                             "master weights; AmpScaler dynamic loss scaling (GradScaler semantics on the device)",
+               "value": round(args.batch * world * args.amp_steps / adt, 3), "unit": "samples/sec",
+               "ms_per_step": round(adt / args.amp_steps * 1e3, 3), "steps": args.amp_steps, "final_loss": float(amp_loss.detach()),
+               "loss_scale": scaler.get_scale()}
     if rank_prof is not None:
         roofline_note = (f"HIP events around every launch of this kernel in {len(hooked)} of the {args.steps} steps of the timed region ("
                          f"{'every step' if every == 1 else 'every second step'}: an event pair costs the stream two marker packets); it was chosen, and the per-kernel table below measured, "
@@ -598,6 +635,8 @@ def main():
                                                    "note": "same launches in the 2 extra steps with the stream overlaps off"}
         if other is not None:
             out["other_math"] = other
+        if amp is not None:
+            out["amp"] = amp
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_grid, args.cpu_baseline_batch)

@@ -170,6 +170,12 @@ int rd_conv_fwd(const float *in, int in_rows, int Cin, const float *weight_k, in
  * into bf16 hi + lo while staged, three bf16 MFMAs per product, fp32 accumulate (~4e-6 relative error, 5x fewer matrix cycles). */
 int rd_set_conv_math(int mode);
 int rd_get_conv_math(void);
+/* Mixed precision inside mode 1: terms = 3 (default) is bf16x3; terms = 1 keeps only the hi * hi MFMA term -- operands rounded to bf16,
+ * fp32 accumulation, fp32 storage (~2.4e-3 per product): the arithmetic of torch.cuda.amp.autocast convolutions, which the reference's
+ * `--use_amp` training loop runs under (tools/train_utils/train_utils.py:23,57-64), at a third of the matrix-core work.  The 32-channel
+ * wavefront kernels (conv_small.hip) keep three terms. */
+int rd_set_mfma_terms(int terms);
+int rd_get_mfma_terms(void);
 
 /* Pre-split operands for the bf16x3 kernels.  "Split format": every 16-byte group of 4 consecutive fp32 elements is replaced by
  * [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] as bf16 (hi = bf16(x), lo = bf16(x - hi)) -- same size, same addressing, so a tensor is

@@ -15,6 +15,7 @@ void set_error(const char *fmt, ...);
 // each output element has exactly ONE contributing block, or run their own ordered variant.  Results then do not depend on how
 // kernels of different streams interleave; speed is not a goal of this mode.
 extern int g_deterministic;
+extern int g_mfma_single;          // rd_set_mfma_terms(1): the bf16x3 kernels keep only the hi * hi product
 
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();

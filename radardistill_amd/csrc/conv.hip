@@ -304,6 +304,7 @@ static int conv_fwd_impl(const float *in, int in_rows, int Cin, const float *wei
     ConvArgs a{in, in_rows, Cin, weight_k, taps, bias, out, out_rows, Cout, *idx, scale, shift, residual, relu, stats};
     a.in_split = in_split;
     a.w_split = w_split;
+    a.x1 = g_mfma_single;
     hipStream_t st = S(stream);
     dim3 block(256);
     if (w_split == 2) {          // weights in fragment-major split format (RD_LAYOUT_FRAG): only the kernels that read fragments from L2

@@ -335,8 +335,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
                     // small terms first, then the dominant one
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    if (!a.x1) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
@@ -504,6 +506,7 @@ struct WgradArgsB3 {
     float *gw;
     int rows_per_block;
     int in_split, go_split;   // operands already in split format (rd_split_bf16)
+    int x1;                   // 1: hi * hi term only (rd_set_mfma_terms)
 };
 
 // TN = Cin tile (128, or 64 for Cin <= 64 layers such as the batched CenterHead first conv); the Cout tile is always 128.
@@ -682,8 +685,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_b3(const WgradArgsB3 a) {
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        if (!a.x1) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        }
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                     }
             }
@@ -873,8 +878,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_tr_b3(const WgradArgsB3 a
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        if (!a.x1) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        }
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                     }
             }
@@ -900,7 +907,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_tr_b3(const WgradArgsB3 a
 
 int launch_wgrad_b3(const float *in, int in_rows, int Cin, const float *go, int out_rows, int Cout, int taps, const rd_conv_index *idx, float *gw,
                     int rows_per_block, int64_t chunks, int tiles, int cin_tile, int in_split, int go_split, hipStream_t st) {
-    WgradArgsB3 a{in, in_rows, Cin, go, out_rows, Cout, taps, *idx, gw, rows_per_block, in_split, go_split};
+    WgradArgsB3 a{in, in_rows, Cin, go, out_rows, Cout, taps, *idx, gw, rows_per_block, in_split, go_split, g_mfma_single};
     dim3 grid((unsigned)chunks, (unsigned)tiles);
     static const bool tr_off = getenv("RD_WGRAD_TR") && getenv("RD_WGRAD_TR")[0] == '0';          // A/B switch: the first-generation kernel
     if (idx->mode != 3 && !tr_off) {
@@ -1075,8 +1082,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_d3_b3(const ConvArgs a, const i
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NI; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        if (!a.x1) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        }
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                     }
             }

@@ -24,6 +24,8 @@ struct ConvArgs {
     // bf16x3 kernels only: operand already in "split format" (rd_split_bf16): every 16-byte group of 4 channels holds
     // [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] as bf16 instead of 4 floats -- same size, same addressing, no in-loop split
     int in_split = 0, w_split = 0;
+    // bf16x3 kernels: 1 = keep only the hi*hi term (plain bf16 products, fp32 accumulate: the mixed-precision mode of rd_set_mfma_terms)
+    int x1 = 0;
 };
 
 __device__ __forceinline__ int src_row(const ConvArgs &a, int j, int t) {

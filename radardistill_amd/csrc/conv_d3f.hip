@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_d3f_b3(const ConvArgs a, const 
     const int b = row_tile / (tiles_y * tiles_x), y0 = ((row_tile / tiles_x) % tiles_y) * TY, x0 = (row_tile % tiles_x) * TX;
     const int n0 = col_tile * BN;
     const int fr = lane & 31, fh = lane >> 5;
+    const bool x1 = a.x1 != 0;
     const int kchunks = a.Cin / KC, c16n = a.Cin >> 4;
 
     f32x16 acc[MI][NI];
@@ -120,14 +121,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_d3f_b3(const ConvArgs a, const 
             bh[j] = __builtin_bit_cast(bf16x8, S.v[j][0]);
             bl[j] = __builtin_bit_cast(bf16x8, S.v[j][1]);
         }
+        if (!x1) {          // wave-uniform: the two correction terms of bf16x3 (rd_set_mfma_terms(1) keeps only hi * hi)
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l[i], bh[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l[i], bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[i], bl[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[i], bl[j], acc[i][j], 0, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll

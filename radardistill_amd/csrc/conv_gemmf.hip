@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3f(const ConvArgs a) {
     if (!xcd_tile((a.out_rows + BM - 1) / BM, (a.Cout + BN - 1) / BN, row_tile, col_tile)) return;
     const int m0 = row_tile * BM, n0 = col_tile * BN;
     const int fr = lane & 31, fh = lane >> 5;
+    const bool x1 = a.x1 != 0;
     const int cblocks = a.Cin / GK, c16n = a.Cin >> 4;          // 64-channel blocks per tap; k16 blocks per tap
 
     // ---- TABLE: stage the table slice, find the taps that have a source row in this tile
@@ -129,14 +130,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3f(const ConvArgs a) {
             bh[j] = __builtin_bit_cast(bf16x8, S.v[j][0]);
             bl[j] = __builtin_bit_cast(bf16x8, S.v[j][1]);
         }
+        if (!x1) {          // wave-uniform: the two correction terms of bf16x3 (rd_set_mfma_terms(1) keeps only hi * hi)
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l[i], bh[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l[i], bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[i], bl[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[i], bl[j], acc[i][j], 0, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll

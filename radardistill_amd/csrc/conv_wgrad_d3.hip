@@ -42,6 +42,7 @@ struct WgradD3Args {
     float *gw;
     int B, H, W, Cin, Cout;
     int tiles_per_block, n_ci_tiles;
+    int x1;          // 1: hi * hi term only (rd_set_mfma_terms)
 };
 
 __device__ __forceinline__ void split4(const f32x4 v, bf16x4 &hi, bf16x4 &lo) {
@@ -142,8 +143,10 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_d3_b3(const WgradD3Args a
             for (int t = 0; t < 9; ++t) {
                 const int off = ((2 * kc + t / 3) * WD_HX + t % 3) * 32;
                 const bf16x8 bh = tr_frag(Xh + off), bl = tr_frag(Xl + off);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                if (!a.x1) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                }
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
             }
         }
@@ -223,7 +226,7 @@ bool launch_wgrad_d3_b3(const float *in, int in_rows, int Cin, const float *go, 
     }
     const int tpb = (int)cdiv(total_tiles, chunks);
     chunks = cdiv(total_tiles, tpb);
-    WgradD3Args a{in, go, gw, (int)B, ix->Hout, ix->Wout, Cin, Cout, tpb, n_ci};
+    WgradD3Args a{in, go, gw, (int)B, ix->Hout, ix->Wout, Cin, Cout, tpb, n_ci, g_mfma_single};
     k_conv_wgrad_d3_b3<<<dim3((unsigned)chunks, (unsigned)n_cc), 512, WD_LDS_BYTES, st>>>(a);
     return true;
 }

@@ -16,9 +16,19 @@ void set_error(const char *fmt, ...) {
 
 using namespace rd;
 
-namespace rd { int g_deterministic = 0; }
+namespace rd { int g_deterministic = 0; int g_mfma_single = 0; }
 extern "C" int rd_set_deterministic(int on) { rd::g_deterministic = on ? 1 : 0; return RD_OK; }
 extern "C" int rd_get_deterministic(void) { return rd::g_deterministic; }
+// Mixed-precision arithmetic of the bf16x3 kernels (rd_set_conv_math(1)): terms = 3 (default) forms a product from the three bf16 MFMA
+// terms hi*hi + hi*lo + lo*hi (fp32-class, ~4e-6); terms = 1 keeps hi*hi only -- operands rounded to bf16, fp32 accumulation and fp32
+// storage, ~2.4e-3 per product: the arithmetic torch autocast gives the reference's convolutions under --use_amp
+// (tools/train_utils/train_utils.py:57-58), at a third of the matrix-core work.
+extern "C" int rd_set_mfma_terms(int terms) {
+    RD_REQUIRE(terms == 1 || terms == 3, "rd_set_mfma_terms: 1 (plain bf16 products) or 3 (bf16x3), got %d", terms);
+    rd::g_mfma_single = terms == 1 ? 1 : 0;
+    return RD_OK;
+}
+extern "C" int rd_get_mfma_terms(void) { return rd::g_mfma_single ? 1 : 3; }
 extern "C" const char *rd_last_error(void) { return rd::g_err; }
 extern "C" int rd_abi_version(void) { return 3; }
 // Fork: `to` waits for everything enqueued on `from` so far.  One library-owned event per waiting stream, re-recorded on every call (a

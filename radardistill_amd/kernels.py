@@ -1220,6 +1220,16 @@ def get_conv_math():
     return _CONV_MATH[0]
 
 
+def set_mfma_terms(terms):
+    """3 (default): bf16x3 products.  1: plain bf16 products (hi * hi only), fp32 accumulate and storage -- the `--use_amp` arithmetic
+    (only meaningful with set_conv_math('bf16x3'))."""
+    check(native.lib().rd_set_mfma_terms(int(terms)), "rd_set_mfma_terms")
+
+
+def get_mfma_terms():
+    return native.lib().rd_get_mfma_terms()
+
+
 # ------------------------------------------------------------------------------------------ CenterHead loss (all heads, fused)
 def center_loss_fwd(cfg, maps, heatmaps, inds, masks, target_boxes, gt_box):
     """maps (B, H, W, NO); stacked targets of rd_center_targets.  -> (out (4*nh + 1,), scale (4*nh,), ws) -- see rd_center_loss_fwd."""

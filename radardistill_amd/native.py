@@ -83,6 +83,8 @@ SIGNATURES = {
                                    ctypes.POINTER(ConvIndex), _P, ctypes.POINTER(ConvIndex), _P, _P, _P, _P, _P, _P, _P]),
     "rd_set_conv_math": (c_int, [c_int]),
     "rd_get_conv_math": (c_int, []),
+    "rd_set_mfma_terms": (c_int, [c_int]),
+    "rd_get_mfma_terms": (c_int, []),
     "rd_split_bf16": (c_int, [_P, c_i64, _P, _P]),
     "rd_weight_layout_split": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "rd_weight_layout_multi": (c_int, [_P, c_int, _P]),

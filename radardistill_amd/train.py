@@ -425,8 +425,9 @@ class AmpScaler:
     train_utils.py:23,57-64; torch defaults growth 2.0, backoff 0.5, growth interval 2000) without host synchronisation: the scale
     and the growth counter live on the device; unscale_ + clip + step are the fused optimizer's own launches (g / S inside the norm
     and Adam kernels, a non-finite norm skips the update); update() is four tiny device ops.
-    The arithmetic of this build's kernels is not changed by autocast (fp32 storage, fp32 / bf16x3 products): what --use_amp keeps
-    here is the loop's control flow and the skipped-step semantics."""
+    The arithmetic under --use_amp is `autocast()` below: the convolution / linear products of forward AND backward run on operands
+    rounded to bf16 (one MFMA term instead of bf16x3's three) with fp32 accumulation; activations, gradients and master weights stay
+    fp32 in memory (torch's autocast stores half-precision activations: storage here is wider, the products are the same class)."""
 
     def __init__(self, device, init_scale=2.0 ** 16, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, enabled=True):
         self.enabled = bool(enabled)
@@ -458,6 +459,31 @@ class AmpScaler:
         self._inv.copy_((1.0 / self._scale).reshape(1))
 
 
+class autocast:
+    """`with autocast(enabled):` -- the arithmetic of the reference's `torch.cuda.amp.autocast(enabled=use_amp)` block
+    (tools/train_utils/train_utils.py:57-58) for this build's kernels: MFMA convolutions / GEMMs take bf16-rounded operands
+    (rd_set_conv_math(1) + rd_set_mfma_terms(1)), fp32 accumulate.  Unlike torch's context it must also cover `backward()`: the data and
+    weight gradient kernels read the switch when they are launched.  Restores the previous modes on exit."""
+
+    def __init__(self, enabled=True):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        from . import kernels as K
+        if self.enabled:
+            self._prev = (K.get_conv_math(), K.get_mfma_terms())
+            K.set_conv_math("bf16x3")
+            K.set_mfma_terms(1)
+        return self
+
+    def __exit__(self, *exc):
+        from . import kernels as K
+        if self.enabled:
+            K.set_conv_math(self._prev[0])
+            K.set_mfma_terms(self._prev[1])
+        return False
+
+
 def use_training_stream(device, priority=-1):
     """Make a HIGH-priority HIP stream the current stream of `device` for the training loop (call once, before the first step) and
     return it.  The step's critical path -- student forward, BatchNorm backward passes, data gradients -- then has its workgroups
@@ -477,13 +503,17 @@ def train_step(model, optimizer, lr_scheduler, model_func, batch, accumulated_it
     lr_scheduler.step(accumulated_iter)
     model.train()
     optimizer.zero_grad()
-    loss, tb_dict, disp_dict = model_func(model, batch)
-    if scaler is not None and scaler.enabled:
-        scaler.scale(loss).backward()
+    amp = scaler is not None and scaler.enabled
+    with autocast(enabled=amp):          # (forward and backward: see autocast)
+        loss, tb_dict, disp_dict = model_func(model, batch)
+        if amp:
+            scaler.scale(loss).backward()
+        else:
+            loss.backward()
+    if amp:
         scaler.step(optimizer)
         scaler.update()
     else:
-        loss.backward()
         optimizer.step()
     return loss, tb_dict
 

@@ -560,6 +560,118 @@ def test_bf16x3_conv_math_parity(golden_dir):
         K.set_conv_math("f32")
 
 
+@pytest.mark.parametrize("shape", ["dense3x3", "gemm", "sparse", "strided"])
+def test_amp_single_term_products_equal_bf16_rounded_operands(shape):
+    """rd_set_mfma_terms(1) -- the `--use_amp` arithmetic (train.autocast): every MFMA convolution kernel forms its products from the
+    operands ROUNDED TO bf16 and accumulates in fp32.  Forward, data gradient and weight gradient of a dense 3x3, a 1-tap GEMM, a
+    sub-manifold sparse and a strided dense convolution against fp64 convolutions of the bf16-rounded operands (1e-5: only the fp32
+    accumulation order differs), and the distance to the un-rounded result is the expected ~2^-9 per operand."""
+    from radardistill_amd import autograd as A, kernels as K, sparse as SP
+    g = np.random.default_rng(3)
+    B, H, W, Cin, Cout = 2, 24, 32, 64, 128
+    rnd = lambda t: t.bfloat16().double()
+    K.set_conv_math("bf16x3")
+    K.set_mfma_terms(1)
+    try:
+        assert K.get_mfma_terms() == 1
+        if shape == "sparse":
+            n = 900
+            keys = np.sort(g.choice(B * H * W, size=n, replace=False))
+            idx = np.stack([keys // (H * W), (keys // W) % H, keys % W], axis=1).astype(np.int32)
+            x = torch.from_numpy(g.normal(size=(n, Cin)).astype(np.float32))
+            w = torch.from_numpy((g.normal(size=(Cout, 3, 3, Cin)) / np.sqrt(9 * Cin)).astype(np.float32))
+            conv = SP.SubMConv2d(Cin, Cout, 3, padding=1, bias=False).to(DEV)
+            with torch.no_grad():
+                conv.weight.copy_(w)
+            xd = x.to(DEV).requires_grad_(True)
+            A.begin_step(torch.device(DEV))
+            out = conv(SP.SparseConvTensor(xd, torch.from_numpy(idx).to(DEV), [H, W], B)).features
+            go = torch.from_numpy(g.normal(size=tuple(out.shape)).astype(np.float32))
+            (out * go.to(DEV)).sum().backward()
+            from oracle import sparse as osp
+            nbr = osp.subm_rulebook(idx, (H, W))
+            xr, wr = rnd(x).requires_grad_(True), rnd(w).requires_grad_(True)
+            ref = osp.sparse_conv(xr, nbr, wr, None)
+            exact = osp.sparse_conv(x.double(), nbr, w.double(), None)
+            (ref * go.double()).sum().backward()
+            # gradients: the kernels round grad_out to bf16 as well -- compare against fp64 products of rounded operands
+            xg, wg = rnd(x).requires_grad_(True), rnd(w).requires_grad_(True)
+            r2 = osp.sparse_conv(xg, nbr, wg, None)
+            gx_ref = torch.autograd.grad((r2 * rnd(go)).sum(), xg, retain_graph=True)[0]
+            gw_ref = torch.autograd.grad((r2 * rnd(go)).sum(), wg)[0]
+            got = (out.detach().cpu().double(), xd.grad.cpu().double(), conv.weight.grad.cpu().double())
+        else:
+            k, s_, p_ = {"dense3x3": (3, 1, 1), "gemm": (1, 1, 0), "strided": (3, 2, 1)}[shape]
+            x = torch.from_numpy(g.normal(size=(B, Cin, H, W)).astype(np.float32))
+            w = torch.from_numpy((g.normal(size=(Cout, Cin, k, k)) / np.sqrt(k * k * Cin)).astype(np.float32))
+            spec = A.dense_conv_spec(B, H, W, k, k, s_, p_)
+            xd = x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().to(DEV).requires_grad_(True)
+            wp = torch.nn.Parameter(w.to(DEV))
+            A.begin_step(torch.device(DEV))
+            out = A.conv(xd, wp, None, spec, Cout)
+            Ho, Wo = spec.out_hw
+            go = torch.from_numpy(g.normal(size=(B, Cout, Ho, Wo)).astype(np.float32))
+            (out * go.permute(0, 2, 3, 1).reshape(-1, Cout).to(DEV)).sum().backward()
+            ref = F.conv2d(rnd(x), rnd(w), None, s_, p_)
+            exact = F.conv2d(x.double(), w.double(), None, s_, p_)
+            xg, wg = rnd(x).requires_grad_(True), rnd(w).requires_grad_(True)
+            r2 = F.conv2d(xg, wg, None, s_, p_)
+            gx_ref, gw_ref = torch.autograd.grad((r2 * rnd(go)).sum(), (xg, wg))
+            rows = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])
+            ref, exact, gx_ref = rows(ref), rows(exact), rows(gx_ref)
+            got = (out.detach().cpu().double(), xd.grad.cpu().double(), wp.grad.cpu().double())
+        torch.cuda.synchronize()
+        rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+        assert rel(got[0], ref) < 1e-5, ("forward vs bf16-rounded operands", rel(got[0], ref))
+        assert 5e-4 < rel(got[0], exact) < 8e-3, ("forward vs exact: plain bf16 products expected", rel(got[0], exact))
+        assert rel(got[1], gx_ref) < 1e-5, ("data gradient", rel(got[1], gx_ref))
+        assert rel(got[2], gw_ref) < 1e-5, ("weight gradient", rel(got[2], gw_ref))
+    finally:
+        K.set_mfma_terms(3)
+        K.set_conv_math("f32")
+
+
+def test_amp_training_step_autocast_and_loss_scaling():
+    """The reference's `--use_amp` iteration (tools/train_utils/train_utils.py:57-64) through train.train_step(scaler=AmpScaler):
+    forward and backward under train.autocast (bf16 products), scaled loss, unscale + clip + Adam in the fused optimizer.  Loss and tb
+    entries stay within 2e-2 of the fp32-class step, every gradient is finite, parameters move, and the modes are restored."""
+    from radardistill_amd import kernels as K
+    from radardistill_amd.pcdet.models import model_fn_decorator
+    from radardistill_amd.train import AmpScaler, build_optimizer, build_scheduler, train_step
+    grid, B = 128, 2
+    batch = make_batch(batch_size=B, n_lidar=300, n_radar=700, n_boxes=10, grid=grid, seed=5)
+    fn = model_fn_decorator()
+    res = {}
+    for amp in (False, True):
+        model, cfg, *_ = _build_pillarnet(grid)
+        sd = model.state_dict(); seeded_fill_(sd, seed=77); model.load_state_dict(sd)
+        model = model.to(DEV)
+        opt = build_optimizer(model, cfg.OPTIMIZATION)
+        sched, _ = build_scheduler(opt, 100, 1, -1, cfg.OPTIMIZATION)
+        scaler = AmpScaler(torch.device(DEV), init_scale=2.0 ** 10, enabled=amp)
+        K.set_conv_math("bf16x3")
+        try:
+            before = {k: p.detach().clone() for k, p in model.named_parameters() if p.requires_grad}
+            loss, tb = train_step(model, opt, sched, fn, {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in batch.items()}, 0,
+                                  scaler=scaler if amp else None)
+            torch.cuda.synchronize()
+            assert K.get_conv_math() == "bf16x3" and K.get_mfma_terms() == 3          # autocast restored the modes
+            moved = sum(int(not torch.equal(p.detach(), before[k])) for k, p in model.named_parameters() if p.requires_grad)
+            grads_ok = all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
+            res[amp] = (float(loss), {k: float(v) for k, v in tb.items()}, moved, grads_ok, float(opt.norm_out[0]))
+        finally:
+            K.set_mfma_terms(3)
+            K.set_conv_math("f32")
+    (l0, tb0, m0, ok0, n0), (l1, tb1, m1, ok1, n1) = res[False], res[True]
+    assert ok0 and ok1 and m1 > 400 and m0 > 400
+    assert abs(l1 - l0) <= 2e-2 * abs(l0), (l0, l1)
+    for k, v in tb0.items():
+        if np.isfinite(v) and abs(v) > 1e-3:
+            assert abs(tb1[k] - v) <= 5e-2 * abs(v) + 1e-3, (k, v, tb1[k])
+    assert np.isfinite(n1) and abs(n1 - n0) <= 0.25 * n0          # the unscaled gradient norm (g / S inside the norm kernel)
+    assert l1 != l0          # the arithmetic really changed
+
+
 def test_teacher_prefetch_gives_the_same_step():
     """PillarNet.prefetch_teacher (teacher branch of the NEXT batch enqueued between backward and optimizer.step) against the plain
     forward on the same batches: BIT-IDENTICAL loss values and gradients (reductions in fixed order, rd_set_deterministic), over three
