@@ -357,7 +357,10 @@ __device__ __forceinline__ void nconv_wgrad_body(const NconvArgs &a, float *lds,
             }
         return;
     }
-    // combine the 16 pixel groups in LDS ([n][c][t], the output layout), then one global atomic per element
+    // Combine the 16 pixel groups, then one global atomic per element.  A wave holds 4 pixel groups (lanes 16 g + l16): they are summed
+    // with two cross-lane shuffles per value, and only lanes 0..15 of each wave add to the LDS image ([n][c][t], the output layout) --
+    // 4-way contention and 16x fewer LDS atomics than every lane adding its own value (PMC round 2: this kernel ran at 0.39 TB/s, 10x
+    // its streaming time: 27.6 k same-address LDS atomics per workgroup, serialised 16 deep).
     for (int i = threadIdx.x; i < N * NC_CB * 9; i += 256) red[i] = 0.f;
     __syncthreads();
 #pragma unroll
@@ -365,7 +368,12 @@ __device__ __forceinline__ void nconv_wgrad_body(const NconvArgs &a, float *lds,
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) atomicAdd(&red[(n * NC_CB + 4 * l16 + j) * 9 + t], acc[n][t][j]);
+            for (int j = 0; j < 4; ++j) {
+                float v = acc[n][t][j];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if ((threadIdx.x & 63) < 16) atomicAdd(&red[(n * NC_CB + 4 * l16 + j) * 9 + t], v);
+            }
     __syncthreads();
     for (int i = threadIdx.x; i < N * NC_CB * 9; i += 256) {
         const float v = red[i];
