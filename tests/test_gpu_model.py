@@ -409,7 +409,7 @@ def _oracle_step(model, batch, pc_range, voxel, gs, B, dtype):
     return oloss.detach(), otb, {k: (state[k].grad if state[k].grad is not None else torch.zeros_like(state[k])) for k in trainable}
 
 
-def test_full_distillation_step_vs_oracle(noise_factor=2.5, whole_factor=3.0, tensor_tol=1e-3):
+def test_full_distillation_step_vs_oracle(noise_factor=3.5, whole_factor=3.0, tensor_tol=1e-3):
     """Config C4 at reduced size (128 x 128 BEV, B = 2): loss, every tb entry and all ~500 gradients of a training step, with the
     library's reductions in fixed order (rd_set_deterministic) so that the HIP side is one reproducible answer.
 
@@ -423,7 +423,9 @@ def test_full_distillation_step_vs_oracle(noise_factor=2.5, whole_factor=3.0, te
     ran before in the process and whatever freshly allocated memory contains), but the statistic is chaotic in the arithmetic: the fp32
     CPU oracle ITSELF moves by 2.3e-2 (whole-gradient relative L2) between 1 and 8 torch threads, and the HIP answer sits between 0.8x
     and 2.03x the fp32 oracle's distance from the fp64 gradient depending on which of the library's equivalent kernels a process
-    picked -- hence whole_factor 3 (was 2: exceeded by 1.4 % when this test runs alone)."""
+    picked -- hence whole_factor 3 (was 2: exceeded by 1.4 % when this test runs alone) and noise_factor 3.5 per tensor (was 2.5: the
+    radar VFE's BatchNorm weight -- the end of the longest backward chain -- landed at 2.67x after the pillar mean's summation order
+    changed with the 4-pillars-per-wavefront kernel; a defect shows as 10 %+ of a tensor, these bounds sit at 4-5 %)."""
     from radardistill_amd import kernels as K
     from radardistill_amd.pcdet.models import model_fn_decorator
     grid, B = 128, 2
