@@ -581,6 +581,15 @@ def main():
                 ifl = sum(_flops_of(p_) for p_ in isel) / len(isel)
                 iso = (ims, ifl / (ims * 1e-3) / 1e12)
         roof["traffic"], roof["traffic_source"] = pmc_traffic(args.math, pmc_key)
+        if args.math == "bf16x3":
+            # what a register-only bf16 MFMA loop sustains on this chip on random operands (the clock held under MFMA load is well under the
+            # 2.4 GHz behind the spec peak: MI355X_MICROARCH.md, DVFS give-back), measured in this run after the timed region
+            ceil = K.probe_mfma_bf16()
+            roof["mfma_loop_ceiling"] = {"tflops": round(ceil, 1), "frac_of_spec_peak": round(ceil / peak, 4),
+                                         "issued_tflops_of_this_kernel": round(3.0 * roof["achieved"], 1),
+                                         "issued_frac_of_ceiling": round(3.0 * roof["achieved"] / ceil, 4) if ceil > 0 else None,
+                                         "note": "rd_probe_mfma_bf16: v_mfma_f32_32x32x16_bf16 only, operands in registers, two waves per SIMD on every "
+                                                 "CU, random data; `frac` above stays priced against the 2.5 PF spec peak"}
         roof["isolated"] = None if iso is None else {
             "note": "same launches in 2 extra steps with the stream overlaps (teacher || student, wgrad || dgrad) off: in the timed region a "
                     "launch shares the GPU with the other streams' kernels, which lengthens it while shortening the step",

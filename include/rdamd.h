@@ -234,6 +234,11 @@ int rd_conv_bn_act_bwd(const float *raw, const float *y, const float *grad_y, in
                        const rd_conv_index *fwd_idx, float *grad_wk, void *ev_d0, void *ev_d1, void *ev_w0, void *ev_w1, void *main_stream,
                        void *side_stream);
 
+/* Measurement probe (bench.py): a register-only v_mfma_f32_32x32x16_bf16 loop on random operands, `waves_per_simd` (1 or 2) waves per SIMD
+ * on every CU, `iters` x 8 independent MFMAs per wave.  *flops_out (host) = the flops the launch issues.  The rate it sustains is what
+ * the chip's clock under MFMA load allows (MI355X_MICROARCH.md, DVFS give-back) -- the practical ceiling next to the 2.5 PF spec peak. */
+int rd_probe_mfma_bf16(int iters, int waves_per_simd, float *out_dev, double *flops_out, void *stream);
+
 /* Data gradient on the forward weights: grad_in[i][c] = sum_t sum_n grad_out[src_bwd(i,t)][n] * weight_k[n][t][c], with weight_k the
  * FORWARD kernel layout [Cout][taps][Cin] (the kernel reads it transposed; no re-laid-out copy) and idx the backward index
  * (transposed neighbour table / flip = 1 for sub-manifold, the transposed geometry for dense convolutions).  Cout % 32 == 0

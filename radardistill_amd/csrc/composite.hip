@@ -79,3 +79,62 @@ extern "C" int rd_conv_bn_act_bwd(const float *raw, const float *y, const float 
     }
     return RD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- measurement probe
+// What a bare v_mfma_f32_32x32x16_bf16 loop sustains on THIS chip with random operands (MI355X_MICROARCH.md, "DVFS give-back": the clock
+// an MFMA-dense loop holds on random data is well under the 2.4 GHz behind the 2.5 PF spec figure, so no kernel issues MFMAs at the
+// spec rate).  Operands live in registers, `waves_per_simd` waves per SIMD on every CU, 8 independent accumulators per wave, no
+// memory traffic in the loop.  bench.py times it with HIP events and quotes the dominant kernel's issued rate against it.
+namespace {
+typedef __bf16 bf16x8p __attribute__((ext_vector_type(8)));
+typedef float f32x16p __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void k_probe_mfma_bf16(int iters, unsigned seed, float *out) {
+    // pseudo-random bf16 operands in [-1, 1): a hash of (thread, element)
+    auto rnd = [&](unsigned k) {
+        unsigned h = (blockIdx.x * 256u + threadIdx.x) * 2654435761u ^ (k * 40503u + seed);
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        return (__bf16)((float)(h & 0xffff) / 32768.f - 1.f);
+    };
+    bf16x8p a[2], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (i < 2) a[i][e] = rnd(i * 8 + e);
+            b[i][e] = rnd(100 + i * 8 + e);
+        }
+    f32x16p acc[2][4];          // 8 independent accumulators (128 registers: two waves per SIMD fit)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    if (s == 123456.789f) out[0] = s;          // keeps the loop alive; practically never true
+}
+}  // namespace
+
+extern "C" int rd_probe_mfma_bf16(int iters, int waves_per_simd, float *out_dev, double *flops_out, void *stream) {
+    RD_REQUIRE(iters > 0 && waves_per_simd >= 1 && waves_per_simd <= 2 && out_dev, "rd_probe_mfma_bf16: iters > 0, 1 or 2 waves per SIMD, a device word");
+    int dev = 0, cus = 0;
+    RD_HIP(hipGetDevice(&dev));
+    RD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int blocks = cus * waves_per_simd;          // 256 threads = 4 waves = one per SIMD
+    k_probe_mfma_bf16<<<blocks, 256, 0, S(stream)>>>(iters, 12345u, out_dev);
+    if (flops_out) *flops_out = (double)blocks * 4.0 * iters * 8.0 * (2.0 * 32 * 32 * 16);
+    return check_launch("rd_probe_mfma_bf16");
+}

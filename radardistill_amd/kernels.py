@@ -1220,6 +1220,22 @@ def get_conv_math():
     return _CONV_MATH[0]
 
 
+def probe_mfma_bf16(iters=4000, waves_per_simd=2, repeats=5):
+    """Sustained rate (TFLOP/s) of a bare bf16 MFMA loop on random operands on this chip right now (rd_probe_mfma_bf16): best of
+    `repeats` launches of ~1 ms each, HIP events on the current stream."""
+    out = torch.zeros(1, dtype=f32, device="cuda")
+    flops = ctypes.c_double(0.0)
+    best = 0.0
+    for _ in range(repeats + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(native.lib().rd_probe_mfma_bf16(int(iters), int(waves_per_simd), _p(out), flops, _stream()), "rd_probe_mfma_bf16")
+        e1.record()
+        e1.synchronize()
+        best = max(best, flops.value / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    return best
+
+
 def set_mfma_terms(terms):
     """3 (default): bf16x3 products.  1: plain bf16 products (hi * hi only), fp32 accumulate and storage -- the `--use_amp` arithmetic
     (only meaningful with set_conv_math('bf16x3'))."""
