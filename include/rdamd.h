@@ -234,6 +234,20 @@ int rd_conv_bn_act_bwd(const float *raw, const float *y, const float *grad_y, in
                        const rd_conv_index *fwd_idx, float *grad_wk, void *ev_d0, void *ev_d1, void *ev_w0, void *ev_w1, void *main_stream,
                        void *side_stream);
 
+/* Geometry prelude of one branch as two calls around the step's single device->host read (composite.hip).  They issue exactly the
+ * launches of rd_voxelize / rd_rankgrid_downsample_grid / rd_rankgrid_coords / rd_nbr_subm / rd_nbr_strided / rd_nbr_strided_T, in that
+ * order; replaces the per-layer index-pair construction spconv does inside pillar_backbone's SubMConv2d / SparseConv2d(k3, s2, p1)
+ * layers (pcdet/models/backbones_3d/spconv_backbone_2d.py:60-140, dynamic_pillar_vfe.py:193-240 for the pillar grid).
+ *   rd_geometry_begin : rankgrid / point_row as rd_voxelize; rankgrid_down[l] (host array of n_down device pointers, each
+ *       rd_rankgrid_bytes(batch * H_l * W_l) bytes, H_{l+1} = (H_l - 1) / 2 + 1) receives level l + 1; scalars_dev (int32, 2 + n_down)
+ *       = {pillars, in-range points, rows of level 1, ..., rows of level n_down}.
+ *   rd_geometry_finish: rankgrid[0 .. n_down], rows[0 .. n_down] (host) from the read; coords[l] (rows[l] x 3), nbr_subm[l] (rows[l] x 9),
+ *       nbr_down[l] (rows[l+1] x 9: inputs of each output row) and, when nbr_up != NULL, nbr_up[l] (rows[l] x 9: the transposed table). */
+int rd_geometry_begin(const float *points, int n_points, int n_feat, int batch, int gx, int gy, float x0, float y0, float vx, float vy,
+                      uint32_t *rankgrid, int32_t *point_row, int n_down, uint32_t *const *rankgrid_down, int32_t *scalars_dev, void *stream);
+int rd_geometry_finish(const uint32_t *const *rankgrid, int batch, int gx, int gy, int n_down, const int32_t *rows, int32_t *const *coords,
+                       int32_t *const *nbr_subm, int32_t *const *nbr_down, int32_t *const *nbr_up, void *stream);
+
 /* Measurement probe (bench.py): a register-only v_mfma_f32_32x32x16_bf16 loop on random operands, `waves_per_simd` (1 or 2) waves per SIMD
  * on every CU, `iters` x 8 independent MFMAs per wave.  *flops_out (host) = the flops the launch issues.  The rate it sustains is what
  * the chip's clock under MFMA load allows (MI355X_MICROARCH.md, DVFS give-back) -- the practical ceiling next to the 2.5 PF spec peak. */

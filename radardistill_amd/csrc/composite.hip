@@ -138,3 +138,89 @@ extern "C" int rd_probe_mfma_bf16(int iters, int waves_per_simd, float *out_dev,
     if (flops_out) *flops_out = (double)blocks * 4.0 * iters * 8.0 * (2.0 * 32 * 32 * 16);
     return check_launch("rd_probe_mfma_bf16");
 }
+
+// ---------------------------------------------------------------------------------------------- geometry prelude
+// The index work of one branch of a training step (pcdet's DynamicPillarVFE voxelisation + the active-site sets and rulebooks of the
+// sparse PillarNet encoder: spconv's SubMConv2d / SparseConv2d(k3, s2, p1) index pairs -- pillar_backbone.py / spconv_backbone_2d of
+// the reference build them lazily layer by layer) as TWO calls around the step's single device->host read:
+//   rd_geometry_begin : points -> rank grid + point rows, then the rank grid of every stride-2 level below it (static launch shapes),
+//                       and the sizes the host needs to allocate the rest -- pillars, in-range points, rows per level -- gathered
+//                       into one small device array;
+//   rd_geometry_finish: with those sizes known: coordinates and the SubM table of every level, the strided table and its transpose
+//                       between consecutive levels.
+// Same kernels, same order as the separate entry points (results are bit-identical by construction); what goes away is ~40 wrapper
+// calls, ~25 small allocations and a dozen torch scalar ops per step at the one place where the GPU waits for the host
+// (tools/diag/stream_timeline.py, round 3: main queue idle for the first 3-4 ms of a step).
+namespace {
+struct GeometryLevels {          // kernel argument block: device pointers + count-word offsets of up to 8 levels
+    const uint32_t *rg[8];
+    int64_t count_word[8];
+};
+__global__ void k_geometry_scalars(const int32_t *point_row, int n_points, int n_levels, GeometryLevels lv, int32_t *scalars) {
+    // scalars[0] = pillars, [1] = in-range points (atomic, zeroed by the caller), [2 + l] = rows of level l + 1
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int c = 0;
+    for (int p = i; p < n_points; p += gridDim.x * blockDim.x) c += point_row[p] >= 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(scalars + 1, c);
+    if (i < n_levels) scalars[i == 0 ? 0 : 1 + i] = (int32_t)lv.rg[i][lv.count_word[i]];
+}
+inline int down(int v) { return (v + 2 - 3) / 2 + 1; }
+}  // namespace
+
+extern "C" int rd_geometry_begin(const float *points, int n_points, int n_feat, int batch, int gx, int gy, float x0, float y0, float vx,
+                                 float vy, uint32_t *rankgrid, int32_t *point_row, int n_down, uint32_t *const *rankgrid_down,
+                                 int32_t *scalars_dev, void *stream) {
+    RD_REQUIRE(n_down >= 0 && n_down <= 7 && (n_down == 0 || rankgrid_down) && scalars_dev, "rd_geometry_begin: 0..7 levels below the pillar grid, a scalars array");
+    int rc = rd_voxelize(points, n_points, n_feat, batch, gx, gy, x0, y0, vx, vy, rankgrid, point_row, stream);
+    if (rc) return rc;
+    GeometryLevels lv{};
+    lv.rg[0] = rankgrid;
+    // the pillar grid is x-major (rows in (b, cx, cy) key order) with H = gy, W = gx; levels below are y-major
+    const uint32_t *src = rankgrid;
+    int H = gy, W = gx, xmajor = 1;
+    auto words = [](int64_t cells) { return (cells + 31) / 32; };
+    lv.count_word[0] = 2 * words((int64_t)batch * H * W);
+    for (int l = 0; l < n_down; ++l) {
+        const int Ho = down(H), Wo = down(W);
+        RD_REQUIRE(rankgrid_down[l], "rd_geometry_begin: rank grid of level %d is NULL", l + 1);
+        rc = rd_rankgrid_downsample_grid(src, batch, H, W, xmajor, Ho, Wo, rankgrid_down[l], stream);
+        if (rc) return rc;
+        lv.rg[l + 1] = rankgrid_down[l];
+        lv.count_word[l + 1] = 2 * words((int64_t)batch * Ho * Wo);
+        src = rankgrid_down[l], H = Ho, W = Wo, xmajor = 0;
+    }
+    hipStream_t st = S(stream);
+    RD_HIP(hipMemsetAsync(scalars_dev, 0, (2 + n_down) * 4, st));
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv((int64_t)n_points, 256 * 8), 512));
+    k_geometry_scalars<<<blocks, 256, 0, st>>>(point_row, n_points, 1 + n_down, lv, scalars_dev);
+    return check_launch("rd_geometry_begin");
+}
+
+extern "C" int rd_geometry_finish(const uint32_t *const *rankgrid, int batch, int gx, int gy, int n_down, const int32_t *rows,
+                                  int32_t *const *coords, int32_t *const *nbr_subm, int32_t *const *nbr_down, int32_t *const *nbr_up,
+                                  void *stream) {
+    RD_REQUIRE(n_down >= 0 && n_down <= 7 && rankgrid && rows && coords && nbr_subm, "rd_geometry_finish: level arrays are required");
+    int Hs[8], Ws[8];
+    Hs[0] = gy, Ws[0] = gx;
+    for (int l = 1; l <= n_down; ++l) Hs[l] = down(Hs[l - 1]), Ws[l] = down(Ws[l - 1]);
+    int rc;
+    for (int l = 0; l <= n_down; ++l) {
+        RD_REQUIRE(rows[l] >= 0 && (rows[l] == 0 || (coords[l] && nbr_subm[l])), "rd_geometry_finish: level %d has %d rows but no coords / table", l, rows[l]);
+        rc = rd_rankgrid_coords(rankgrid[l], batch, Hs[l], Ws[l], l == 0, coords[l], rows[l], stream);
+        if (rc) return rc;
+        rc = rd_nbr_subm(coords[l], rows[l], rankgrid[l], batch, Hs[l], Ws[l], l == 0, nbr_subm[l], stream);
+        if (rc) return rc;
+    }
+    for (int l = 0; l < n_down; ++l) {
+        RD_REQUIRE(nbr_down && (rows[l + 1] == 0 || nbr_down[l]), "rd_geometry_finish: strided table of level %d is NULL", l);
+        rc = rd_nbr_strided(coords[l + 1], rows[l + 1], rankgrid[l], batch, Hs[l], Ws[l], l == 0, nbr_down[l], stream);
+        if (rc) return rc;
+        if (nbr_up && nbr_up[l]) {
+            rc = rd_nbr_strided_T(coords[l], rows[l], rankgrid[l + 1], batch, Hs[l + 1], Ws[l + 1], nbr_up[l], stream);
+            if (rc) return rc;
+        }
+    }
+    return RD_OK;
+}

@@ -114,6 +114,75 @@ def nbr_strided_T(in_coords, out_rg, batch, Ho, Wo):
     return nbrT
 
 
+# ---- geometry prelude: one call before and one after the step's only device->host read (composite.hip)
+_GEOMETRY_PLANS = {}
+
+
+def _align(n, a=64):
+    return (n + a - 1) // a * a
+
+
+def geometry_plan(batch, gx, gy, n_down):
+    """Static part of a branch's index allocation: [(H, W)] per level and the int32 offsets / sizes of its rank grids."""
+    key = (batch, gx, gy, n_down)
+    plan = _GEOMETRY_PLANS.get(key)
+    if plan is None:
+        dims = [(gy, gx)]
+        for _ in range(n_down):
+            H, W = dims[-1]
+            dims.append(((H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1))
+        sizes = [native.lib().rd_rankgrid_bytes(int(batch * H * W)) // 4 for H, W in dims]
+        offs, o = [], 0
+        for sz in sizes:
+            offs.append(o)
+            o += _align(sz)
+        plan = _GEOMETRY_PLANS[key] = (dims, sizes, offs, o)
+    return plan
+
+
+def geometry_begin(points, batch, gx, gy, x0, y0, vx, vy, n_down, scalars):
+    """rd_geometry_begin: points -> (rank grids of level 0 .. n_down, point_row), all views of ONE allocation; `scalars` (int32 device,
+    2 + n_down) receives {pillars, in-range points, rows of each level below}."""
+    _chk(points, f32, "points", 2)
+    n, nf = points.shape[0], points.shape[1] - 1
+    dims, sizes, offs, total = geometry_plan(batch, gx, gy, n_down)
+    block = torch.empty(total + n, dtype=i32, device=points.device)
+    rgs = [block[o:o + sz] for o, sz in zip(offs, sizes)]
+    point_row = block[total:total + n]
+    base = block.data_ptr()
+    down = (ctypes.c_void_p * max(n_down, 1))(*[base + 4 * o for o in offs[1:]])
+    check(native.lib().rd_geometry_begin(_p(points), n, nf, batch, gx, gy, x0, y0, vx, vy, base, base + 4 * total, n_down, down, _p(scalars),
+                                         _stream()), "rd_geometry_begin")
+    return rgs, point_row, dims
+
+
+def geometry_finish(rgs, batch, gx, gy, rows):
+    """rd_geometry_finish: with the rows of every level known -> (coords, SubM tables, strided tables, transposed strided tables),
+    views of ONE allocation."""
+    L = len(rgs)
+    rows = [int(r) for r in rows]
+    offs, o = [], 0
+    for l in range(L):
+        lv = [o, o + _align(3 * rows[l])]                         # coords, SubM table
+        o = lv[1] + _align(9 * rows[l])
+        if l + 1 < L:
+            lv += [o, o + _align(9 * rows[l + 1])]                # strided table (rows of level l + 1), its transpose (rows of level l)
+            o = lv[3] + _align(9 * rows[l])
+        offs.append(lv)
+    block = torch.empty(max(o, 1), dtype=i32, device=rgs[0].device)
+    base = block.data_ptr()
+    PA = ctypes.c_void_p * L
+    coords = [block[lv[0]:lv[0] + 3 * r].view(r, 3) for lv, r in zip(offs, rows)]
+    subm = [block[lv[1]:lv[1] + 9 * r].view(r, 9) for lv, r in zip(offs, rows)]
+    down = [block[offs[l][2]:offs[l][2] + 9 * rows[l + 1]].view(rows[l + 1], 9) for l in range(L - 1)]
+    up = [block[offs[l][3]:offs[l][3] + 9 * rows[l]].view(rows[l], 9) for l in range(L - 1)]
+    check(native.lib().rd_geometry_finish(PA(*[rg.data_ptr() for rg in rgs]), batch, gx, gy, L - 1, (ctypes.c_int32 * L)(*rows),
+                                          PA(*[base + 4 * lv[0] for lv in offs]), PA(*[base + 4 * lv[1] for lv in offs]),
+                                          PA(*([base + 4 * offs[l][2] for l in range(L - 1)] + [0])),
+                                          PA(*([base + 4 * offs[l][3] for l in range(L - 1)] + [0])), _stream()), "rd_geometry_finish")
+    return coords, subm, down, up
+
+
 # ------------------------------------------------------------------------------------------ pillar VFE
 def vfe_pillar_mean(points, point_row, n_pillars):
     acc = torch.empty((n_pillars, 4), dtype=f32, device=points.device)

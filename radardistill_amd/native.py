@@ -82,6 +82,8 @@ SIGNATURES = {
     "rd_conv_bn_act_bwd": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, c_int, c_int,
                                    ctypes.POINTER(ConvIndex), _P, ctypes.POINTER(ConvIndex), _P, _P, _P, _P, _P, _P, _P]),
     "rd_probe_mfma_bf16": (c_int, [c_int, c_int, _P, _P, _P]),
+    "rd_geometry_begin": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_f32, c_f32, c_f32, c_f32, _P, _P, c_int, _P, _P, _P]),
+    "rd_geometry_finish": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "rd_set_conv_math": (c_int, [c_int]),
     "rd_get_conv_math": (c_int, []),
     "rd_set_mfma_terms": (c_int, [c_int]),

@@ -115,6 +115,26 @@ class DynamicPillarVFESimple2D(VFETemplate):
         batch_dict[self.OUT_PREFIX + '_vfe_geometry'] = (points, rg, point_row, coords, P, n_valid)
         return level
 
+    def prelude_begin(self, batch_dict, n_down, scalars):
+        """geometry_begin + the rank grids of the `n_down` encoder levels below the pillar grid in ONE library call
+        (rd_geometry_begin); `scalars` (int32 device, 2 + n_down) receives the sizes the host reads."""
+        points = self._points(batch_dict)
+        B = int(batch_dict['batch_size'])
+        rgs, point_row, dims = K.geometry_begin(points, B, self.grid_x, self.grid_y, self.pc_range[0], self.pc_range[1], self.voxel_x,
+                                                self.voxel_y, n_down, scalars)
+        return points, rgs, point_row, dims, B
+
+    def prelude_finish(self, batch_dict, state, vals):
+        """vals = [pillars, in-range points, rows of each level below]: coordinates + all neighbour tables of the branch in ONE
+        library call (rd_geometry_finish); returns the pillar `_Level` with its pyramid attached."""
+        points, rgs, point_row, dims, B = state
+        P, n_valid = int(vals[0]), int(vals[1])
+        coords, subm, down, up = K.geometry_finish(rgs, B, self.grid_x, self.grid_y, [P, *vals[2:]])
+        level = SP.pyramid_from_tables(rgs, dims, B, coords, subm, down, up)
+        SP.register_rankgrid(coords[0], rgs[0], True, level)
+        batch_dict[self.OUT_PREFIX + '_vfe_geometry'] = (points, rgs[0], point_row, coords[0], P, n_valid)
+        return level
+
     def forward(self, batch_dict, **kwargs):
         geo = batch_dict.pop(self.OUT_PREFIX + '_vfe_geometry', None)
         if geo is None:

@@ -213,30 +213,40 @@ class PillarNet(Detector3DTemplate):
                 gs.wait_event(ready)
             else:
                 gs.wait_stream(main)
-            begun = [v.geometry_begin(batch_dict) for v in vfes]
-            # every level's rank grid is marked from the grid above it with static launch shapes, so ALL sizes of both branches
-            # (pillars, in-range points, 3 pyramid levels) come back in ONE read
-            marked = [SP.mark_pyramid(st[1], True, st[3], v.grid_y, v.grid_x, 3) for v, (st, _) in zip(vfes, begun)]
-            scalars = [t for (_, sc), mk in zip(begun, marked) for t in (*sc, *[m[3].long() for m in mk])]
-            vals = torch.stack(scalars).tolist()                                                 # the only read (geometry stream only)
-            levels = []
-            for i, (v, (st, _), mk) in enumerate(zip(vfes, begun, marked)):
-                base = 5 * i
-                lvl = v.geometry_finish(batch_dict, st, int(vals[base]), int(vals[base + 1]))
-                SP.finish_pyramid(lvl, mk, vals[base + 2:base + 5])
-                levels.append(lvl)
+            if os.environ.get('RD_GEOM_COMPOSITE', '1') != '0':
+                # two library calls per branch around the read (rd_geometry_begin / rd_geometry_finish), one allocation each
+                scal = torch.empty(5 * len(vfes), dtype=torch.int32, device=dev)
+                begun = [v.prelude_begin(batch_dict, 3, scal[5 * i:5 * i + 5]) for i, v in enumerate(vfes)]
+                vals = scal.tolist()                                                             # the only read (geometry stream only)
+                levels = [v.prelude_finish(batch_dict, st, vals[5 * i:5 * i + 5]) for i, (v, st) in enumerate(zip(vfes, begun))]
+                shared = [(st[0], st[1][0], lvl.coords) for st, lvl in zip(begun, levels)]       # points + the two allocations
+            else:
+                begun = [v.geometry_begin(batch_dict) for v in vfes]
+                # every level's rank grid is marked from the grid above it with static launch shapes, so ALL sizes of both branches
+                # (pillars, in-range points, 3 pyramid levels) come back in ONE read
+                marked = [SP.mark_pyramid(st[1], True, st[3], v.grid_y, v.grid_x, 3) for v, (st, _) in zip(vfes, begun)]
+                scalars = [t for (_, sc), mk in zip(begun, marked) for t in (*sc, *[m[3].long() for m in mk])]
+                vals = torch.stack(scalars).tolist()                                             # the only read (geometry stream only)
+                levels, shared = [], []
+                for i, (v, (st, _), mk) in enumerate(zip(vfes, begun, marked)):
+                    base = 5 * i
+                    lvl = v.geometry_finish(batch_dict, st, int(vals[base]), int(vals[base + 1]))
+                    SP.finish_pyramid(lvl, mk, vals[base + 2:base + 5])
+                    levels.append(lvl)
+                    shared.append((st[0], st[2], *lvl.tensors()))
             done = torch.cuda.Event()
             done.record(gs)
         main.wait_event(done)
         # tensors allocated on the geometry stream are read on the main / teacher streams: tell the caching allocator
+        # (record_stream acts on the allocation, so one view per allocation is enough)
         streams = [main]
         if getattr(self, '_teacher_stream', None) is None and self.no_grad_module:
             self._teacher_stream = torch.cuda.Stream(dev, priority=int(os.environ.get('RD_TEACHER_PRIO', '0')))
         if getattr(self, '_teacher_stream', None) is not None:
             streams.append(self._teacher_stream)
-        for v, (st, _), lvl in zip(vfes, begun, levels):
-            st[0].record_stream(gs)                                     # the points were read on the geometry stream
-            for t in (st[0], st[2], *lvl.tensors()):                    # (st[0] may be a converted copy made on that stream)
+        for tensors in shared:
+            tensors[0].record_stream(gs)                                # the points were read on the geometry stream
+            for t in tensors:                                           # (they may be a converted copy made on that stream)
                 for s_ in streams:
                     t.record_stream(s_)
 

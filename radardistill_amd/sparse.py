@@ -104,6 +104,20 @@ def finish_pyramid(level, marked, counts):
         level.subm_spec()
 
 
+def pyramid_from_tables(rgs, dims, batch, coords, subm, down, up):
+    """The `_Level` chain of one branch from the tables rd_geometry_finish filled (kernels.geometry_finish): level 0 is the x-major
+    pillar grid, the levels below are y-major.  Equal, table for table, to finish_pyramid() on the same rank grids."""
+    levels = [_Level(c, rg, l == 0, batch, H, W) for l, (c, rg, (H, W)) in enumerate(zip(coords, rgs, dims))]
+    for lvl, nbr in zip(levels, subm):
+        lvl._subm = A.ConvSpec(9, lvl.n, lvl.n, K.conv_index_table(nbr, flip=False), K.conv_index_table(nbr, flip=True), 0, keep=(nbr,),
+                               fwd_nbr=nbr, bwd_nbr=nbr)
+    for l, (nbr, nbrT) in enumerate(zip(down, up)):
+        spec = A.ConvSpec(9, levels[l].n, levels[l + 1].n, K.conv_index_table(nbr), K.conv_index_table(nbrT), 0, keep=(nbr, nbrT),
+                          fwd_nbr=nbr, bwd_nbr=nbrT)
+        levels[l]._down = (levels[l + 1], spec)
+    return levels[0]
+
+
 def build_pyramids(levels, n_down):
     """SubM tables + `n_down` stride-2 levels below each of `levels`, in lockstep: ONE device->host read per depth for all branches."""
     cur = list(levels)

@@ -795,6 +795,46 @@ def test_full_size_voxelizer_and_rulebook_pyramid_bit_exact():
         idx, (H, W) = oidx, oshape
 
 
+@pytest.mark.parametrize("B,grid,n_lidar", [(8, 512, 35000), (2, 96, 600), (1, 40, 0)])
+def test_geometry_prelude_calls_equal_the_separate_entry_points(B, grid, n_lidar):
+    """rd_geometry_begin / rd_geometry_finish (two calls per branch around the step's one read) fill, word for word, the rank grids,
+    point rows, sizes, coordinates and the 4 + 3 + 3 neighbour tables that the separate entry points do; at the bench size, on a ragged
+    small grid, and for a sample without any point (every level empty)."""
+    A, K, SP = _mods()
+    pc_range, voxel, gs = bench_geometry(grid)
+    gx, gy = int(gs[0]), int(gs[1])
+    if n_lidar:
+        pts = torch.from_numpy(make_batch(batch_size=B, n_lidar=n_lidar, n_radar=50, n_boxes=5, grid=grid, seed=4)["points"]).to(DEV)
+    else:
+        pts = torch.zeros((0, 6), device=DEV)
+    rg, point_row = K.voxelize(pts, B, gx, gy, pc_range[0], pc_range[1], voxel[0], voxel[1])
+    P = int(K.rankgrid_count_tensor(rg, B * gx * gy))
+    marked = SP.mark_pyramid(rg, True, B, gy, gx, 3)
+    rows = [P] + [int(m[3]) for m in marked]
+    level = SP._Level(K.rankgrid_coords(rg, B, gy, gx, True, P), rg, True, B, gy, gx)
+    SP.finish_pyramid(level, marked, rows[1:])
+
+    scal = torch.full((5,), -7, dtype=torch.int32, device=DEV)
+    rgs, point_row2, dims = K.geometry_begin(pts, B, gx, gy, pc_range[0], pc_range[1], voxel[0], voxel[1], 3, scal)
+    assert scal.tolist() == [P, int((point_row >= 0).sum()), *rows[1:]]
+    assert torch.equal(point_row, point_row2)
+    for a, b in zip([rg] + [m[0] for m in marked], rgs):
+        assert torch.equal(a, b)
+    coords, subm, down, up = K.geometry_finish(rgs, B, gx, gy, rows)
+    top = SP.pyramid_from_tables(rgs, dims, B, coords, subm, down, up)
+    ref, got = level, top
+    for l in range(4):
+        assert (ref.n, ref.H, ref.W, ref.xmajor) == (got.n, got.H, got.W, got.xmajor) and ref.n == rows[l]
+        assert torch.equal(ref.coords, got.coords) and torch.equal(ref._subm.fwd_nbr, got._subm.fwd_nbr)
+        assert (got._subm.fwd_ix.flip, got._subm.bwd_ix.flip) == (ref._subm.fwd_ix.flip, ref._subm.bwd_ix.flip)
+        if l == 3:
+            assert got._down is None
+            break
+        assert torch.equal(ref._down[1].fwd_nbr, got._down[1].fwd_nbr) and torch.equal(ref._down[1].bwd_nbr, got._down[1].bwd_nbr)
+        assert (got._down[1].in_rows, got._down[1].out_rows) == (ref._down[1].in_rows, ref._down[1].out_rows)
+        ref, got = ref._down[0], got._down[0]
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 21, 19, 64, 96),       # ragged map, one 64-channel ci tile, Cout not a tile multiple
                                             (8, 64, 64, 256, 256),     # the DenseEnc shape of the bench (512 pixel tiles)
                                             (1, 8, 8, 32, 64),         # a single tile, half-empty ci tile

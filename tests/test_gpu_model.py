@@ -329,12 +329,22 @@ def test_center_head_concatenated_leaves_accumulate_and_follow_the_parameters():
         A.end_forward()
         return loss.detach()
 
-    step(m)
-    assert m._branch_plan[0]._store['ok']
-    g1 = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
-    step(m)                                           # no zero_grad: the second pass accumulates
+    # (a) in the library's fixed-order mode: the two passes are then the same arithmetic, and the sum must be 2 x the first gradient.
+    # With the default atomics the BatchNorm statistics of the two passes differ in their last bits, and this input has a pixel of
+    # heads_list.3.hm whose pre-activation sits within an ulp of zero: its ReLU mask flips in ~7 % of the runs and moves one output
+    # channel of hm.0.0.weight by 6e-2 (tools/diag/head_accum_stress.py, round 3: always that channel, always that amount, in either
+    # pass, and the single-stream recomputation agrees with the other pass) -- arithmetic noise, not an accumulation defect.
+    from radardistill_amd import kernels as K
+    K.set_deterministic(True)
+    try:
+        step(m)
+        assert m._branch_plan[0]._store['ok']
+        g1 = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+        step(m)                                           # no zero_grad: the second pass accumulates
+    finally:
+        K.set_deterministic(False)
     for k, p in m.named_parameters():
-        close(p.grad, 2 * g1[k], rtol=2e-3, atol=2e-4 * float(g1[k].abs().max()) + 1e-7, what=f"accumulated grad {k}")
+        close(p.grad, 2 * g1[k], rtol=1e-5, atol=1e-6 * float(g1[k].abs().max()) + 1e-9, what=f"accumulated grad {k}")
     # (b) in-place parameter update (what torch optimizers do), then compare with the per-branch path of a copy
     with torch.no_grad():
         for p in m.parameters():
@@ -425,7 +435,10 @@ def test_full_distillation_step_vs_oracle(noise_factor=3.5, whole_factor=3.0, te
     and 2.03x the fp32 oracle's distance from the fp64 gradient depending on which of the library's equivalent kernels a process
     picked -- hence whole_factor 3 (was 2: exceeded by 1.4 % when this test runs alone) and noise_factor 3.5 per tensor (was 2.5: the
     radar VFE's BatchNorm weight -- the end of the longest backward chain -- landed at 2.67x after the pillar mean's summation order
-    changed with the 4-pillars-per-wavefront kernel; a defect shows as 10 %+ of a tensor, these bounds sit at 4-5 %)."""
+    changed with the 4-pillars-per-wavefront kernel; a defect shows as 10 %+ of a tensor, these bounds sit at 4-5 %).
+    The oracle's distance is itself one draw per summation order -- radar_backbone_3d.conv1.0.bn2.weight: 1.2e-2 / 2.2e-2 / 3.4e-2 of
+    its norm with 2 / 4 / 1 torch threads, HIP 6.3e-2 -- and the host of the GPU box decides the default thread count, so the bound
+    uses the largest of three draws (default, 1 and 4 threads) instead of whichever one the machine happens to produce."""
     from radardistill_amd import kernels as K
     from radardistill_amd.pcdet.models import model_fn_decorator
     grid, B = 128, 2
@@ -434,6 +447,17 @@ def test_full_distillation_step_vs_oracle(noise_factor=3.5, whole_factor=3.0, te
     batch = make_batch(batch_size=B, n_lidar=300, n_radar=700, n_boxes=10, grid=grid, seed=5)   # sparse lidar: AFD is NaN by definition when every 8x cell is lidar-active
     o32 = _oracle_step(model, batch, pc_range, voxel, gs, B, torch.float32)
     o64 = _oracle_step(model, batch, pc_range, voxel, gs, B, torch.float64)
+    # the yardstick is the fp32 oracle's OWN distance from the fp64 gradient, and that is one draw of a chaotic statistic per summation
+    # order: two more draws (1 and 4 torch threads; per tensor the 1-thread draw is up to 2.9x the 8-thread one), the largest counts
+    threads = torch.get_num_threads()
+    g32_draws = [o32[2]]
+    try:
+        for th in (1, 4):
+            if th != threads:
+                torch.set_num_threads(th)
+                g32_draws.append(_oracle_step(model, batch, pc_range, voxel, gs, B, torch.float32)[2])
+    finally:
+        torch.set_num_threads(threads)
     model = model.to(DEV)
     model.train()
     K.set_deterministic(True)
@@ -452,23 +476,27 @@ def test_full_distillation_step_vs_oracle(noise_factor=3.5, whole_factor=3.0, te
     g32, g64 = o32[2], o64[2]
     gscale = max(float(g.abs().max()) for g in g64.values())
     worst, at_1e3 = ("", 0.0), 0
-    e_hip2 = e_o322 = ref2 = 0.0
+    e_hip2 = ref2 = 0.0
+    e_o322 = [0.0] * len(g32_draws)
     for k, ref in g64.items():
         a = named[k].grad
         assert a is not None, k
         e_hip = float((a.detach().cpu().double() - ref).norm())
-        e_o32 = float((g32[k].double() - ref).norm())
+        e_draws = [float((g[k].double() - ref).norm()) for g in g32_draws]
+        e_o32 = max(e_draws)
         rn = float(ref.norm())
-        e_hip2 += e_hip ** 2; e_o322 += e_o32 ** 2; ref2 += rn ** 2
+        e_hip2 += e_hip ** 2; ref2 += rn ** 2
+        e_o322 = [s_ + e ** 2 for s_, e in zip(e_o322, e_draws)]
         floor = 1e-5 * gscale * (ref.numel() ** 0.5)          # conv biases in front of a BatchNorm: the exact gradient is 0
         bound = max(tensor_tol * rn, noise_factor * e_o32) + floor
         at_1e3 += e_hip <= 1e-3 * rn + floor
         if e_hip / bound > worst[1]:
             worst = (k, e_hip / bound)
         assert e_hip <= bound, (k, "hip vs fp64", e_hip / (rn + 1e-30), "fp32 oracle vs fp64", e_o32 / (rn + 1e-30))
-    whole_hip, whole_o32 = (e_hip2 / ref2) ** 0.5, (e_o322 / ref2) ** 0.5
+    whole_hip, whole_draws = (e_hip2 / ref2) ** 0.5, [(e / ref2) ** 0.5 for e in e_o322]
+    whole_o32 = max(whole_draws)
     print(f"{at_1e3} of {len(g64)} tensors within 1e-3 of the fp64 gradient; worst error / bound {worst}; whole-gradient relative L2: "
-          f"hip {whole_hip:.3e}, fp32 oracle {whole_o32:.3e}")
+          f"hip {whole_hip:.3e}, fp32 oracle draws {[f'{w:.3e}' for w in whole_draws]}")
     assert whole_hip <= max(1e-3, whole_factor * whole_o32), (whole_hip, whole_o32)
     assert int(model.global_step) == 1
 
