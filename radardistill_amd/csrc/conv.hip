@@ -194,6 +194,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
         float csum = 0.f, csq = 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
+            float resv[16];          // residual values first, all in flight together (a load between the stores waits for the store before it)
+            if (a.residual) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    resv[r] = a.residual[(int64_t)min(row, a.out_rows - 1) * a.Cout + min(col, a.Cout - 1)];          // (clamped: unused outside)
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
                     csum += v;
                     csq += v * v;
                     v = fmaf(v, sc, sh);
-                    if (a.residual) v += a.residual[(int64_t)row * a.Cout + col];
+                    if (a.residual) v += resv[r];
                     if (a.relu) v = fmaxf(v, 0.f);
                     a.out[(int64_t)row * a.Cout + col] = v;
                 }

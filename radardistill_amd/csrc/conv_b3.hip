@@ -367,6 +367,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
         float csum = 0.f, csq = 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
+            float resv[16];          // residual values first, all in flight together (a load between the stores waits for the store before it)
+            if (a.residual) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    bool row_ok = row < tile_rows;
+                    if (SUBPIX) {
+                        const int4 q = s_pix[row - m0];
+                        row_ok = q.w != 0;
+                        row = (q.x * a.ix.Hout + 2 * q.y + sp_py) * a.ix.Wout + 2 * q.z + sp_px;
+                    }
+                    resv[r] = a.residual[(int64_t)(row_ok ? row : 0) * a.Cout + min(col, a.Cout - 1)];          // (readable address: unused outside)
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
@@ -381,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_b3(const ConvArgs a) {
                     csum += v;
                     csq += v * v;
                     v = fmaf(v, sc, sh);
-                    if (a.residual) v += a.residual[(int64_t)row * a.Cout + col];
+                    if (a.residual) v += resv[r];
                     if (a.relu) v = fmaxf(v, 0.f);
                     a.out[(int64_t)row * a.Cout + col] = v;
                 }

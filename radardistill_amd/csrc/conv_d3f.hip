@@ -12,6 +12,7 @@
 // [Cin][tap][Cout] orientation), fp32 activations split while staged, identical products and epilogue -- results are bit-identical
 // to the LDS-staged kernel in deterministic order of accumulation (same K order: chunk-major, tap, k16).
 #include <stdlib.h>
+#include <type_traits>
 #include "conv_common.hpp"
 
 using namespace rd;
@@ -33,7 +34,7 @@ __device__ __forceinline__ void split4(const f32x4 v, bf16x4 &hi, bf16x4 &lo) {
     }
 }
 
-template <int TY, int TX, int BN>
+template <int TY, int TX, int BN, int D, bool X1>
 __global__ __launch_bounds__(256, 2) void k_conv_d3f_b3(const ConvArgs a, const int flip) {
     constexpr int BM = TY * TX;
     constexpr int HX = TX + 2, HR = (TY + 2) * HX;
@@ -52,7 +53,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_d3f_b3(const ConvArgs a, const 
     const int b = row_tile / (tiles_y * tiles_x), y0 = ((row_tile / tiles_x) % tiles_y) * TY, x0 = (row_tile % tiles_x) * TX;
     const int n0 = col_tile * BN;
     const int fr = lane & 31, fh = lane >> 5;
-    const bool x1 = a.x1 != 0;
     const int kchunks = a.Cin / KC, c16n = a.Cin >> 4;
 
     f32x16 acc[MI][NI];
@@ -81,17 +81,19 @@ __global__ __launch_bounds__(256, 2) void k_conv_d3f_b3(const ConvArgs a, const 
     }
 
     // One HALF-STEP = one k16 slice of one tap: NI x (hi, lo) weight fragments (4 coalesced 16-byte-per-lane loads at NI = 2), MI x (hi, lo)
-    // halo fragments from LDS, 3 * MI * NI MFMAs.  18 half-steps per chunk; weight fragments travel through a ring of THREE register
-    // sets (requested two half-steps = one tap ahead: 18 % 3 == 0, so a half-step's set is static in the unrolled loop), halo fragments
-    // through TWO (read one half-step ahead).  The compiler's scheduler is pinned with sched_barrier: left alone (252 VGPRs with whole-
-    // tap sets) it sank every load next to its first use to shorten live ranges -- `global_load; s_waitcnt vmcnt(0)` pairs in the ISA.
+    // halo fragments from LDS, 3 * MI * NI MFMAs.  18 half-steps per chunk; weight fragments are requested D half-steps ahead of their
+    // MFMAs into a ring of D + 1 register sets (18 % (D + 1) == 0, so a half-step's set is static in the unrolled loop), halo fragments
+    // go through TWO sets (read one half-step ahead).  The compiler's scheduler is pinned with sched_barrier: left alone (252 VGPRs with
+    // whole-tap sets) it sank every load next to its first use to shorten live ranges -- `global_load; s_waitcnt vmcnt(0)` pairs in the ISA.
     struct BSet {
         uint4 v[NI][2];          // [column block][hi | lo]
     };
     struct ASet {
         bf16x8 h[MI], l[MI];
     };
-    BSet Bq[3];
+    constexpr int RING = D + 1;          // register sets of weight fragments (18 % RING == 0: a half-step's set is static in the unrolled loop)
+    static_assert(18 % RING == 0, "ring position must repeat every chunk");
+    BSet Bq[RING];
     ASet Aq[2];
     auto load_B = [&](BSet &S, int h, int kq) {          // half-step h of chunk kq
         const int tap = h >> 1, ks = h & 1;
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_d3f_b3(const ConvArgs a, const 
             bh[j] = __builtin_bit_cast(bf16x8, S.v[j][0]);
             bl[j] = __builtin_bit_cast(bf16x8, S.v[j][1]);
         }
-        if (!x1) {          // wave-uniform: the two correction terms of bf16x3 (rd_set_mfma_terms(1) keeps only hi * hi)
+        if constexpr (!X1) {          // the two correction terms of bf16x3 (X1: rd_set_mfma_terms(1) keeps only hi * hi)
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -174,29 +176,51 @@ __global__ __launch_bounds__(256, 2) void k_conv_d3f_b3(const ConvArgs a, const 
     };
 
     load_halo(0);
-    load_B(Bq[0], 0, 0);
-    load_B(Bq[1], 1, 0);
+#pragma unroll
+    for (int h = 0; h < D; ++h) load_B(Bq[h % RING], h, 0);
     store_halo(0);
     __syncthreads();
-    for (int kq = 0; kq < kchunks; ++kq) {
-        const bool more = kq + 1 < kchunks;
+    // Two forms of the chunk loop, chosen per tile by measurement (tools/diag/lib_ab.sh, both builds inside one GPU call):
+    //   UNIFORM (64-column tile: the 8192-row layers, few workgroups per CU-second, latency-bound): the chunk body exists twice -- the
+    //     loop's (every chunk but the last: requests the next chunk's weights in its last D half-steps and the next halo at h = 0, splits
+    //     and stores it at h = 9, unconditionally) and the peeled last chunk (no requests) -- and the chunk ends with an LDS-only barrier.
+    //     Inside either body there is no run-time condition around a load: a request under `if (more)` makes the two paths reach the
+    //     following s_waitcnt with different numbers of loads in flight, the compiler waits for the smaller number, and on the taken path
+    //     that is the load it has just issued (ISA: `s_waitcnt vmcnt(0)` at every chunk start); __syncthreads() drains vmcnt as well
+    //     (its fence; loads and stores share the counter on gfx9).  +2 ... +4 % on those layers.
+    //   otherwise (128-column tile, the dominant kernel): one loop with `if (more)` and __syncthreads().  The same change costs this
+    //     tile 3 % (0.1239 -> 0.1283 ms at 8 x 64 x 64, 256 -> 256): with two workgroups per CU the drained loads are covered by the
+    //     other workgroup's MFMAs, and the drain keeps the two workgroups of a CU out of phase.
+    constexpr bool UNIFORM = BN == 64;
+    auto chunk = [&](const int kq, auto last_tag, const bool more) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const bool nxt = UNIFORM ? !LAST : more;          // (a compile-time constant in the UNIFORM form)
         const __bf16 *Abuf = lds + (kq & 1) * 2 * PART;
         read_A(Aq[0], Abuf, 0);
 #pragma unroll
         for (int h = 0; h < 18; ++h) {
-            if (h + 2 < 18) load_B(Bq[(h + 2) % 3], h + 2, kq);
-            else if (more) load_B(Bq[(h + 2) % 3], h + 2 - 18, kq + 1);
-            if (h == 0 && more) load_halo((kq + 1) * KC);          // after this half-step's weight request: no weight wait before h = 2 includes it
+            // weight fragments are requested D half-steps ahead of their MFMAs (the last D requests of a chunk are the next chunk's first)
+            if (h + D < 18) load_B(Bq[(h + D) % RING], h + D, kq);
+            else if (nxt) load_B(Bq[(h + D) % RING], h + D - 18, kq + 1);
+            if (h == 0 && nxt) load_halo((kq + 1) * KC);          // after this half-step's weight request: no weight wait before h = D includes it
             if (h + 1 < 18) read_A(Aq[(h + 1) & 1], Abuf, h + 1);
             __builtin_amdgcn_sched_barrier(0);
-            mfmas(Aq[h & 1], Bq[h % 3]);
+            mfmas(Aq[h & 1], Bq[h % RING]);
             __builtin_amdgcn_sched_barrier(0);
-            if (h == 9 && more) {
+            if (h == 9 && nxt) {
                 store_halo((kq + 1) & 1);          // the other buffer: last read before the previous chunk's closing barrier
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __syncthreads();          // everyone finished reading this chunk's halo and writing the next one
+        // everyone finished reading this chunk's halo and writing the next one
+        if constexpr (UNIFORM) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else __syncthreads();
+    };
+    if constexpr (UNIFORM) {
+        for (int kq = 0; kq + 1 < kchunks; ++kq) chunk(kq, std::false_type{}, true);
+        chunk(kchunks - 1, std::true_type{}, false);
+    } else {
+        for (int kq = 0; kq < kchunks; ++kq) chunk(kq, std::false_type{}, kq + 1 < kchunks);
     }
 
     // ---- epilogue (as k_conv_d3_b3; tile rows are pixels of the (TY, TX) patch)
@@ -215,6 +239,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_d3f_b3(const ConvArgs a, const 
         float csum = 0.f, csq = 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
+            // residual values of the 16 rows first, all in flight together (a load between the stores waits for the store in front of it:
+            // loads and stores share vmcnt)
+            float resv[16];
+            if (a.residual) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    const int gy = y0 + p / TX, gx = x0 + p % TX;
+                    resv[r] = a.residual[((int64_t)(b * H + min(gy, H - 1)) * W + min(gx, W - 1)) * a.Cout + min(col, a.Cout - 1)];          // (clamped: unused outside)
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int p = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
@@ -225,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_d3f_b3(const ConvArgs a, const 
                     csum += v;
                     csq += v * v;
                     v = fmaf(v, sc, sh);
-                    if (a.residual) v += a.residual[row * a.Cout + col];
+                    if (a.residual) v += resv[r];
                     if (a.relu) v = fmaxf(v, 0.f);
                     a.out[row * a.Cout + col] = v;
                 }
@@ -270,7 +305,16 @@ int launch_conv_d3f_b3(const ConvArgs &a, hipStream_t st) {
     static const int tile_env = getenv("RD_D3F_TILE") ? atoi(getenv("RD_D3F_TILE")) : 0;          // diagnostic: 128 / 64 forces the column tile
     const bool wide = tile_env ? tile_env == 128 : (a.Cout >= 128 && big_rows * cdiv(a.Cout, 128) >= 384);
     dim3 block(256);
-    if (wide) k_conv_d3f_b3<8, 16, 128><<<dim3(xcd_grid(big_rows, cdiv(a.Cout, 128))), block, 0, st>>>(a, flip);
-    else k_conv_d3f_b3<8, 16, 64><<<dim3(xcd_grid(big_rows, cdiv(a.Cout, 64))), block, 0, st>>>(a, flip);
+    // weight fragments two half-steps ahead: three and four were measured equal or slower on every shape of the step (tools/diag/d3_ring.sh,
+    // round 3) -- the L2 round trip is covered at two, and the 128-column tile has no registers left for more
+    const dim3 gw(xcd_grid(big_rows, cdiv(a.Cout, 128))), gn(xcd_grid(big_rows, cdiv(a.Cout, 64)));
+#define RD_D3F_LAUNCH(BN_, G_)                                                              \
+    do {                                                                                    \
+        if (a.x1) k_conv_d3f_b3<8, 16, BN_, 2, true><<<G_, block, 0, st>>>(a, flip);        \
+        else k_conv_d3f_b3<8, 16, BN_, 2, false><<<G_, block, 0, st>>>(a, flip);            \
+    } while (0)
+    if (wide) RD_D3F_LAUNCH(128, gw);
+    else RD_D3F_LAUNCH(64, gn);
+#undef RD_D3F_LAUNCH
     return RD_OK;
 }

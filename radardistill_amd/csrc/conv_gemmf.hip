@@ -40,7 +40,7 @@ __device__ __forceinline__ void split4(const f32x4 v, bf16x4 &hi, bf16x4 &lo) {
     }
 }
 
-template <int BM, int BN, bool TABLE>
+template <int BM, int BN, bool TABLE, bool X1>
 __global__ __launch_bounds__(256, 2) void k_gemm_b3f(const ConvArgs a) {
     constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
     constexpr int PART = BM * GROW;                    // bf16 elements of one (hi or lo) tile image
@@ -56,7 +56,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3f(const ConvArgs a) {
     if (!xcd_tile((a.out_rows + BM - 1) / BM, (a.Cout + BN - 1) / BN, row_tile, col_tile)) return;
     const int m0 = row_tile * BM, n0 = col_tile * BN;
     const int fr = lane & 31, fh = lane >> 5;
-    const bool x1 = a.x1 != 0;
     const int cblocks = a.Cin / GK, c16n = a.Cin >> 4;          // 64-channel blocks per tap; k16 blocks per tap
 
     // ---- TABLE: stage the table slice, find the taps that have a source row in this tile
@@ -130,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3f(const ConvArgs a) {
             bh[j] = __builtin_bit_cast(bf16x8, S.v[j][0]);
             bl[j] = __builtin_bit_cast(bf16x8, S.v[j][1]);
         }
-        if (!x1) {          // wave-uniform: the two correction terms of bf16x3 (rd_set_mfma_terms(1) keeps only hi * hi)
+        if constexpr (!X1) {          // the two correction terms of bf16x3 (X1: rd_set_mfma_terms(1) keeps only hi * hi)
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -210,29 +209,36 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3f(const ConvArgs a) {
     }
     __syncthreads();
     for (int kq = 0; kq < kchunks; ++kq) {
+        // The next chunk's requests (weights: half-steps 1..3, activations: half-step 0, split and stored after half-step 2) are issued
+        // UNCONDITIONALLY: in the last chunk they re-read this chunk (valid memory, results unused).  Under `if (more)` the two paths
+        // reach the following s_waitcnt with different numbers of loads in flight and the compiler waits for the smaller number -- on the
+        // taken path that is the load just issued (conv_d3f.hip, round 3: `s_waitcnt vmcnt(0)` at every chunk start).
         const bool more = kq + 1 < kchunks;
         const __bf16 *Abuf = lds + (kq & 1) * 2 * PART;
         bool nt = false;
-        if (more) nt = next_chunk(w16_nxt, kc_nxt);
+        if (more) nt = next_chunk(w16_nxt, kc_nxt);          // (index arithmetic only)
+        else w16_nxt = w16_cur;
         read_A(Aq[0], Abuf, 0);
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             // half-step h + 3: slice 3 of this chunk (h == 0) or slice h - 1 of the next one
             if (h == 0) load_B(Bq[3], w16_cur + 3);
-            else if (more) load_B(Bq[(h + 3) & 3], w16_nxt + h - 1);
-            if (h == 0 && more) load_A(nt, kc_nxt);          // after this half-step's weight request
+            else load_B(Bq[(h + 3) & 3], w16_nxt + h - 1);
+            if (h == 0) load_A(nt, kc_nxt);          // after this half-step's weight request
             if (h + 1 < 4) read_A(Aq[(h + 1) & 1], Abuf, h + 1);
             __builtin_amdgcn_sched_barrier(0);
             mfmas(Aq[h & 1], Bq[h & 3]);
             __builtin_amdgcn_sched_barrier(0);
-            if (h == 2 && more) {
+            if (h == 2) {
                 okmask = ok_next;
                 store_A((kq + 1) & 1);          // the other buffer: last read before the previous chunk's closing barrier
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         w16_cur = w16_nxt;
-        __syncthreads();
+        // LDS-only barrier: __syncthreads() carries a workgroup fence, and loads share vmcnt with stores on gfx9 -- it would drain the
+        // weight fragments and the activation tile requested for the next chunk
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 
     // ---- epilogue (as k_conv_igemm_b3)
@@ -251,6 +257,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3f(const ConvArgs a) {
         float csum = 0.f, csq = 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
+            // residual values of the 16 rows first, all in flight together: a load placed between the stores waits -- loads and stores
+            // share vmcnt -- for the store in front of it (ISA, round 3: `s_waitcnt vmcnt(0)` per element, one HBM round trip each)
+            float resv[16];
+            if (a.residual) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    resv[r] = a.residual[(int64_t)min(row, a.out_rows - 1) * a.Cout + min(col, a.Cout - 1)];          // (clamped: unused outside)
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
@@ -259,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3f(const ConvArgs a) {
                     csum += v;
                     csq += v * v;
                     v = fmaf(v, sc, sh);
-                    if (a.residual) v += a.residual[(int64_t)row * a.Cout + col];
+                    if (a.residual) v += resv[r];
                     if (a.relu) v = fmaxf(v, 0.f);
                     a.out[(int64_t)row * a.Cout + col] = v;
                 }
@@ -302,13 +318,20 @@ static void launch_gemm_tiles(const ConvArgs &a, hipStream_t st) {
     static const int tile_env = getenv("RD_GEMMF_TILE") ? atoi(getenv("RD_GEMMF_TILE")) : 0;          // diagnostic: 128 / 64 forces the row tile
     const int64_t big = cdiv(a.out_rows, 128) * cdiv(a.Cout, 128);
     const bool bm128 = tile_env ? tile_env == 128 : big >= (TABLE ? 384 : 256);
+#define RD_GEMMF_LAUNCH(BM_, BN_)                                                                                                \
+    do {                                                                                                                         \
+        const dim3 grid(xcd_grid(cdiv(a.out_rows, BM_), cdiv(a.Cout, BN_)));                                                     \
+        if (a.x1) k_gemm_b3f<BM_, BN_, TABLE, true><<<grid, block, 0, st>>>(a);                                                  \
+        else k_gemm_b3f<BM_, BN_, TABLE, false><<<grid, block, 0, st>>>(a);                                                      \
+    } while (0)
     if (a.Cout >= 128) {
-        if (bm128) k_gemm_b3f<128, 128, TABLE><<<dim3(xcd_grid(cdiv(a.out_rows, 128), cdiv(a.Cout, 128))), block, 0, st>>>(a);
-        else k_gemm_b3f<64, 128, TABLE><<<dim3(xcd_grid(cdiv(a.out_rows, 64), cdiv(a.Cout, 128))), block, 0, st>>>(a);
+        if (bm128) RD_GEMMF_LAUNCH(128, 128);
+        else RD_GEMMF_LAUNCH(64, 128);
     } else {
-        if (bm128) k_gemm_b3f<128, 64, TABLE><<<dim3(xcd_grid(cdiv(a.out_rows, 128), cdiv(a.Cout, 64))), block, 0, st>>>(a);
-        else k_gemm_b3f<64, 64, TABLE><<<dim3(xcd_grid(cdiv(a.out_rows, 64), cdiv(a.Cout, 64))), block, 0, st>>>(a);
+        if (bm128) RD_GEMMF_LAUNCH(128, 64);
+        else RD_GEMMF_LAUNCH(64, 64);
     }
+#undef RD_GEMMF_LAUNCH
 }
 
 int launch_gemm_b3f(const ConvArgs &a_in, hipStream_t st) {

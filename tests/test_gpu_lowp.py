@@ -182,6 +182,21 @@ def test_dual_branch_forward_and_afd_in_bf16():
         e = _rel_l2(got[k], ref[k].cpu())
         print(k, "bf16 vs fp32 relative L2", e)
         assert e <= 1e-2, (k, e)
+    # the STUDENT branch in bf16 arithmetic as well (round 3): train.autocast = every MFMA product on bf16-rounded operands (one of
+    # bf16x3's three terms), fp32 accumulate and storage -- VFE, sparse encoder, CMA (DCNv2 columns), DenseEnc.  Stated tolerance:
+    # 2e-2 relative L2 on the three student maps the losses read (8 mantissa bits through ~30 layers; measured 4-8e-3).
+    from radardistill_amd.train import autocast
+    with autocast(enabled=True):
+        amp = forward('bf16')
+    for k in ('radar_spatial_features_2d',):
+        e = _rel_l2(amp[k], ref[k].cpu())
+        print(k, "student bf16-product arithmetic vs fp32 relative L2", e)
+        assert e <= 2e-2, (k, e)
+    for k in ('radar_spatial_features_8x_2', 'radar_spatial_features_8x_1'):
+        e = _rel_l2(amp['radar_multi_scale_2d_features'][k], ref['radar_multi_scale_2d_features'][k].cpu())
+        print(k, "student bf16-product arithmetic vs fp32 relative L2", e)
+        assert e <= 2e-2, (k, e)
+    assert K.get_mfma_terms() == 3 and K.get_conv_math() == "f32"          # autocast restored the arithmetic mode
     # AFD: fp32 kernel on fp32 maps vs the bf16-map kernel on bf16 copies of the same three maps
     lid = ref['multi_scale_2d_features']['x_conv4']
     ra = ref['radar_multi_scale_2d_features']['radar_spatial_features_8x_2']
