@@ -633,7 +633,9 @@ def main():
             gbs = by_tot / (ms_tot * 1e-3) / 1e9
             out["roofline_hbm"] = {"bound": "hbm", "kernel": "k_bn_train_fwd (train-mode BatchNorm + residual + ReLU over rows, launches moving >= 16 MB)",
                                    "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                                   "traffic": None, "launches_per_step": len(big) // max(min(prof_steps, 2) if rank_prof is not None else prof_steps, 1),
+                                   "traffic": None, "traffic_note": "the PMC passes average ALL k_bn_train_fwd dispatches (45 per step, most of them the small "
+                                   "sparse-stage ones), this figure only the >= 16 MB launches: no comparable per-launch counter value",
+                                   "launches_per_step": len(big) // max(min(prof_steps, 2) if rank_prof is not None else prof_steps, 1),
                                    "avg_launch_ms": round(ms_tot / len(big), 4), "algorithmic_bytes_per_launch": int(by_tot / len(big)),
                                    "measured": "HIP events around every such launch inside the timed region (other streams' kernels run concurrently)"}
             ibig = [(a.elapsed_time(b), by) for a, b, by, _ in (iso_bn or []) if by >= 16e6]
