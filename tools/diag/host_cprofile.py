@@ -57,6 +57,11 @@ def main():
         pstats.Stats(pr, stream=s).sort_stats(key).print_stats(70)
         print(f"==== sorted by {key} ({args.steps} steps)")
         print(s.getvalue())
+    for pat in ("__getattr__", "_chk", "is_contiguous", "_call_impl"):
+        s = io.StringIO()
+        pstats.Stats(pr, stream=s).sort_stats("tottime").print_callers(pat)
+        print(f"==== callers of {pat}")
+        print("\n".join(l[:200] for l in s.getvalue().splitlines()[:60]))
 
 
 if __name__ == "__main__":
