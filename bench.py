@@ -654,7 +654,7 @@ def main():
             except Exception as e:                      # the baseline is a reported extra; never lose the GPU number to it
                 out["cpu_baseline"] = {"value": None, "unit": "samples/sec", "cores": None, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():          # (world > 1, or the one-rank rehearsal)
         torch.distributed.destroy_process_group()
 
 

@@ -410,6 +410,11 @@ def deliver_grads(leaves, grads):
         cb(leaves)
 
 
+# Off under torch's DistributedDataParallel (dist.data_parallel, RD_DDP=torch): its reducer only sees gradients that pass through the
+# parameters' own AccumulateGrad nodes; gradients handed over as views of a concatenated leaf would count as "unused parameters".
+CONCAT_LEAVES = [True]
+
+
 class ConcatLeaves:
     """Several leaf parameters that one kernel consumes concatenated along dim 0 (the 42 CenterHead branches: weights, biases,
     BatchNorm affines), kept as ONE persistent leaf tensor: refresh() copies the current parameter values in (one launch), the

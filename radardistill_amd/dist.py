@@ -16,9 +16,24 @@ def env_world():
     return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def rehearsal():
+    """RD_DP_REHEARSE=1: run the whole data-parallel path -- process group, parameter broadcast, bucketed flat-buffer all-reduce on the
+    communication stream, presence mask -- in a world of ONE rank.  The collectives then are RCCL's single-rank forms, but every
+    stream hand-over, async work handle and bucket launch of the N > 1 path executes on the GPU (a one-GPU box cannot host two RCCL
+    ranks: "duplicate GPU")."""
+    return os.environ.get("RD_DP_REHEARSE", "0") == "1"
+
+
+def _active():
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or rehearsal())
+
+
 def init_distributed(backend="nccl", device=None):
     world, rank, local_rank = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or rehearsal()) and not dist.is_initialized():
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
@@ -34,7 +49,7 @@ def shard_seed(rank, index, base=0):
 def wrap_ddp(model, local_rank=None):
     """DistributedDataParallel over the trainable parameters only (frozen teacher parameters have requires_grad=False and are
     ignored by the reducer, tools/train.py:174-176)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active():
         return model
     ids = [local_rank] if (local_rank is not None and next(model.parameters()).is_cuda) else None
     return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids)
@@ -42,7 +57,7 @@ def wrap_ddp(model, local_rank=None):
 
 def broadcast_parameters(model, src=0):
     """Rank `src`'s parameters and buffers to every rank, coalesced (what DistributedDataParallel does once at construction)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active():
         return
     tensors = [p.data for p in model.parameters()] + [b.data for b in model.buffers()]
     by_dtype = {}
@@ -69,12 +84,13 @@ def data_parallel(model, optimizer, device_index=None, mode=None):
     .enable_flat_allreduce).  BatchNorm running statistics stay local; rank 0's are what a checkpoint stores, exactly as under
     DDP's broadcast_buffers (rank 0's buffers are never overwritten there either).
     mode "torch" (RD_DDP=torch): torch.nn.parallel.DistributedDataParallel as in tools/train.py:174-176 of the reference."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active():
         return model
     mode = mode or os.environ.get("RD_DDP", "flat")
     if mode == "torch" or not hasattr(optimizer, "enable_flat_allreduce"):
         from . import autograd as A
         A.WGRAD_STREAM[0] = False        # DDP's reducer hooks read every gradient the moment autograd produces it, on the main stream
+        A.CONCAT_LEAVES[0] = False       # ... and only gradients that arrive through the parameters' own AccumulateGrad nodes
         return wrap_ddp(model, device_index)
     broadcast_parameters(model, 0)
     optimizer.enable_flat_allreduce()
@@ -140,7 +156,7 @@ class GradBuckets:
 
 
 def max_over_ranks(seconds, device="cpu"):
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active():
         return float(seconds)
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -149,7 +165,7 @@ def max_over_ranks(seconds, device="cpu"):
 
 def average_scalars(values, device="cpu"):
     """Mean over ranks of a few python floats with ONE collective (data / forward / batch time of the reference's loop)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active():
         return [float(v) for v in values]
     t = torch.tensor(list(values), dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -157,5 +173,5 @@ def average_scalars(values, device="cpu"):
 
 
 def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.barrier()

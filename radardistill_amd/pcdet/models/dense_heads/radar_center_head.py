@@ -166,7 +166,7 @@ class _BranchBatch:
             # parameters of the 42 branches concatenated: persistent leaves whose gradients are handed to the branch parameters as
             # views (autograd.ConcatLeaves); under HIP-graph capture (torch.autograd.grad over the module's own parameters) or with
             # partly frozen branches: torch.cat inside the graph
-            st = None if A.CAPTURING[0] else self._train_store()
+            st = None if (A.CAPTURING[0] or not A.CONCAT_LEAVES[0]) else self._train_store()
 
             def cat(key, mod, name):
                 if st is not None:

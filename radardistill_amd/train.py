@@ -103,6 +103,7 @@ class FusedAdamOneCycle:
         self._amp_used = False
         self.present = None            # data parallelism: per-parameter "some rank has a gradient" mask, all-reduced every step
         self._static_cols = None
+        self._param_ptrs = None
         self.flat_grad = None          # data parallelism: see enable_flat_allreduce()
         self.process_group = None
 
@@ -116,27 +117,39 @@ class FusedAdamOneCycle:
         buffer (laid out like the Adam moments), summed over the ranks (RCCL over xGMI) and the norm / Adam kernels read the averaged
         gradients straight from that buffer (flat_grad, grad_scale = 1 / world).  Parameters must start equal on all ranks
         (dist.broadcast_parameters).
-        overlap (default on, RD_DDP_OVERLAP=0 disables): the buffer is cut into ~bucket_mb (25) MB buckets in reverse parameter order;
-        a post-accumulate-grad hook per parameter counts a bucket down and, when its last gradient exists, packs the bucket (one
+        Default (RD_DDP_OVERLAP unset or 0): ONE pack launch + ONE all-reduce of the whole buffer after backward -- 100 MB over xGMI,
+        0.5-1 ms on the critical path of a 17.4 ms step, and no host work during backward.
+        overlap (RD_DDP_OVERLAP=1): the buffer is cut into ~bucket_mb (25) MB buckets in reverse parameter order; a
+        post-accumulate-grad hook per parameter counts a bucket down and, when its last gradient exists, packs the bucket (one
         launch, rd_pack_grads_list) and starts its all-reduce on a communication stream that first waits for the main and the
-        weight-gradient streams -- the head's 7 MB travel while DenseEnc / CMA / SparseEnc are still in their backward.  step()
-        only waits for the collectives.  Without overlap: one pack launch + one all-reduce after backward."""
+        weight-gradient streams -- the head's 7 MB travel while DenseEnc / CMA / SparseEnc are still in their backward; step()
+        only waits for the collectives.  OFF by default since round 3: rehearsed on the GPU in a world of one rank (dist.rehearsal:
+        every hook, bucket launch and RCCL call executes, the collectives move nothing) the overlapped path costs the host-bound step
+        17.4 -> 19.1 ms with the loop on torch's default stream (265 Python hook calls in the autograd thread + ~0.3 ms per bucket
+        launch) and 24.1 ms with the loop on its high-priority stream (the communication stream's waits for the weight-gradient
+        stream then hold up packets of the stream that shares its hardware queue) -- more than the all-reduce it hides."""
         import os
         from .dist import GradBuckets
         n = int(self.offsets[-1])
-        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
-        self.present = torch.zeros(len(self.params), dtype=torch.float32, device=self.params[0].device)
+        # the presence mask (one float per parameter, see _presence) lives behind the gradients in the same allocation: without
+        # buckets ONE collective per step carries both
+        self._flat_all = torch.zeros(n + len(self.params), dtype=torch.float32, device=self.params[0].device)
+        self.flat_grad = self._flat_all[:n]
+        self.present = self._flat_all[n:]
+        self._presence_fresh = False          # the mask was summed together with the gradients of THIS exchange
         self.process_group = process_group
         if overlap is None:
-            overlap = os.environ.get("RD_DDP_OVERLAP", "1") != "0"
+            overlap = os.environ.get("RD_DDP_OVERLAP", "0") != "0"
         self.buckets = None
         if overlap:
             mb = float(bucket_mb if bucket_mb is not None else os.environ.get("RD_DDP_BUCKET_MB", "25"))
             self.buckets = GradBuckets([p.numel() for p in self.params], int(mb * (1 << 20)))
             self._works = []
             self._work_of = {}
-            # high priority, like the training loop's own stream (use_training_stream): the collectives' few, long-lived workgroups
-            # must not queue behind the compute streams' dispatches
+            self._pack_cache = {}
+            # high priority, like the training loop's own stream.  (Normal priority was measured worse still: 32 ms per step in the
+            # one-rank rehearsal against 24 ms -- whichever hardware queue the communication stream shares, its waits for the
+            # weight-gradient stream hold the packets queued behind them.)
             self._comm_stream = torch.cuda.Stream(self.params[0].device, priority=-1) if self.params[0].is_cuda else None
             # (a bucket is packed mid-backward: _launch_bucket first runs the deferred weight-gradient re-layouts that are due)
             for i, p in enumerate(self.params):
@@ -188,9 +201,14 @@ class FusedAdamOneCycle:
             comm.wait_stream(side)                 # weight gradients are produced on the side stream
         base = self.flat_grad.data_ptr()
         prev = self._work_of.pop(b, None)
-        with torch.cuda.stream(comm):
-            if prev is not None:
-                prev.wait()                        # a dirty bucket is re-packed: its first collective must have left the slice
+        # The pack descriptors of a bucket only depend on where its gradients live, and in steady state the allocator hands every
+        # step's gradients the same addresses: the ctypes arrays are rebuilt (and the gradients re-validated) only when that
+        # signature changes, or every 64th launch (filling ~480 descriptors cost 1.3 ms of host time per step, round 3).
+        grads = [p.grad for p in self.params[lo:hi]]
+        sig = tuple([g.data_ptr() if g is not None else 0 for g in grads])
+        cache = self._pack_cache.get(b)
+        if cache is None or cache[0] != sig or cache[2] >= 64:
+            jobs = []
             for s in range(lo, hi, 128):
                 part = range(s, min(hi, s + 128))
                 arr = (PackJob * len(part))()
@@ -201,7 +219,15 @@ class FusedAdamOneCycle:
                     arr[k].src = g.data_ptr() if g is not None else None
                     arr[k].dst = base + 4 * int(self.offsets[i])
                     arr[k].numel = self.params[i].numel()
-                check(native.lib().rd_pack_grads_list(arr, len(part), _stream()), "rd_pack_grads_list")
+                jobs.append((arr, len(part)))
+            sig = tuple([(p.grad.data_ptr() if p.grad is not None else 0) for p in self.params[lo:hi]])
+            cache = self._pack_cache[b] = [sig, jobs, 0, base]
+        cache[2] += 1
+        with torch.cuda.stream(comm):
+            if prev is not None:
+                prev.wait()                        # a dirty bucket is re-packed: its first collective must have left the slice
+            for arr, n_jobs in cache[1]:
+                check(native.lib().rd_pack_grads_list(arr, n_jobs, _stream()), "rd_pack_grads_list")
             w = dist.all_reduce(self.flat_grad[e0:e1], op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
             self._works.append(w)
             self._work_of[b] = w
@@ -229,7 +255,10 @@ class FusedAdamOneCycle:
             if not g.is_contiguous() or g.dtype != torch.float32:
                 g = p.grad = g.float().contiguous()
             grads.append(g.data_ptr())
-        sig = (tuple(grads), tuple(p.data_ptr() for p in self.params))
+        pp = self._param_ptrs          # parameters keep their storage (optimizers update in place): revalidated by the two ends
+        if pp is None or pp[0] != self.params[0].data_ptr() or pp[-1] != self.params[-1].data_ptr():
+            pp = self._param_ptrs = tuple(p.data_ptr() for p in self.params)
+        sig = (tuple(grads), pp)
         for slot in range(self._ring):
             if self._slot_sig[slot] == sig:
                 return self.table_dev[slot]
@@ -242,7 +271,7 @@ class FusedAdamOneCycle:
         # ctypes fields cost 1 ms per step for ~480 parameters)
         tab = host.numpy().view(np.int64).reshape(len(self.params), 5)
         static = self._static_cols
-        if static is None or static[0] != tuple(p.data_ptr() for p in self.params):
+        if static is None or static[0] != pp:
             m0, v0 = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
             cols = np.empty((len(self.params), 5), dtype=np.int64)
             cols[:, 0] = [p.data_ptr() for p in self.params]
@@ -278,7 +307,9 @@ class FusedAdamOneCycle:
         if table is None:
             table = self._fill_table()
         check(native.lib().rd_pack_grads(_p(table), _p(self.chunks_dev), self.n_chunks, _p(self.flat_grad), _stream()), "rd_pack_grads")
-        dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.process_group)
+        check(native.lib().rd_grad_presence(_p(table), len(self.params), _p(self.present), _stream()), "rd_grad_presence")
+        dist.all_reduce(self._flat_all, op=dist.ReduceOp.SUM, group=self.process_group)          # gradients + presence counts: one collective
+        self._presence_fresh = True
         return self.flat_grad, 1.0 / dist.get_world_size(self.process_group)
 
     def _presence(self, table):
@@ -286,6 +317,9 @@ class FusedAdamOneCycle:
         A parameter without a gradient on THIS rank only (a branch its batch did not use) then takes part like on the other ranks,
         with the averaged gradient from the flat buffer -- same norm, same clip coefficient, same Adam step count everywhere."""
         import torch.distributed as dist
+        if self._presence_fresh:          # summed together with the gradients (allreduce_gradients without buckets)
+            self._presence_fresh = False
+            return self.present
         check(native.lib().rd_grad_presence(_p(table), len(self.params), _p(self.present), _stream()), "rd_grad_presence")
         dist.all_reduce(self.present, op=dist.ReduceOp.MAX, group=self.process_group)
         return self.present

@@ -63,7 +63,7 @@ def main():
     assert torch.equal(buf, ref), f"flat buffer differs from the per-tensor all-reduce: max {float((buf - ref).abs().max())}"
     dist.barrier()
     nb = len(opt.buckets.ranges) if getattr(opt, "buckets", None) is not None else 0
-    if os.environ.get("RD_DDP_OVERLAP", "1") != "0":
+    if getattr(opt, "buckets", None) is not None:          # RD_DDP_OVERLAP=1: the bucketed, overlapped exchange
         assert nb >= 2 and all(v == hi - lo for v, (lo, hi) in zip(opt.buckets.left, opt.buckets.ranges)), "bucket bookkeeping not reset"
     # (c) gradient accumulation: two backward passes, one exchange
     opt.zero_grad()

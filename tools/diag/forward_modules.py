@@ -45,6 +45,14 @@ def main():
     opt = build_optimizer(model, cfg.OPTIMIZATION)
     sched, _ = build_scheduler(opt, 1000, 1, -1, cfg.OPTIMIZATION)
     fn = model_fn_decorator()
+    if os.environ.get("RD_DP_REHEARSE") == "1":          # the data-parallel path in a world of one rank (dist.rehearsal)
+        from radardistill_amd import dist as D
+        D.init_distributed(backend="nccl", device=device)
+        model = D.data_parallel(model, opt, 0)
+        for name in ("_grad_ready", "_launch_bucket", "zero_grad", "step", "allreduce_gradients", "_presence", "_fill_table"):
+            setattr(opt, name, timed("optimizer." + name, getattr(opt, name)))
+        A._flush_deferred_layouts = timed("_flush_deferred_layouts", A._flush_deferred_layouts)
+        A.deliver_grads = timed("deliver_grads", A.deliver_grads)
     batches = [B.device_batch(make_batch(batch_size=batch, n_lidar=35000, n_radar=2000, n_boxes=30, grid=512, seed=i), device) for i in range(2)]
 
     def step(it):
@@ -54,9 +62,27 @@ def main():
         loss.backward()
         opt.step()
 
+    if os.environ.get("RD_DIAG_TRAINING_STREAM") == "1":          # as bench.py: the loop on a high-priority stream
+        from radardistill_amd.train import use_training_stream
+        use_training_stream(device, -1)
+    phase = [0.0, 0.0, 0.0]
+
+    def step(it):          # (phases timed on the host, no device sync)
+        t0 = time.perf_counter()
+        sched.step(it)
+        opt.zero_grad()
+        loss, tb, _ = fn(model, dict(batches[it % 2]))
+        t1 = time.perf_counter()
+        loss.backward()
+        t2 = time.perf_counter()
+        opt.step()
+        t3 = time.perf_counter()
+        phase[0] += t1 - t0; phase[1] += t2 - t1; phase[2] += t3 - t2
+
     for it in range(6):
         step(it)
     torch.cuda.synchronize()
+    phase[:] = [0.0, 0.0, 0.0]
     for m in model.module_list:
         m.forward = timed("module " + m.__class__.__name__, m.forward)
         if hasattr(m, "prepare"):
@@ -75,7 +101,20 @@ def main():
         step(it)
     host = time.perf_counter() - t0
     torch.cuda.synchronize()
-    print(f"B = {batch}: {n} steps, host loop {host / n * 1e3:.2f} ms/step")
+    print(f"B = {batch}: {n} steps, host loop {host / n * 1e3:.2f} ms/step; forward+loss {phase[0] / n * 1e3:.2f}  backward {phase[1] / n * 1e3:.2f}  "
+          f"optimizer {phase[2] / n * 1e3:.2f}")
+    # CPU time of every thread of this process (a busy helper thread -- a collective library's proxy or watchdog -- competes with the
+    # enqueue loop for the box's CPU share)
+    tick = os.sysconf("SC_CLK_TCK")
+    threads = []
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            comm = open(f"/proc/self/task/{tid}/comm").read().strip()
+            f = open(f"/proc/self/task/{tid}/stat").read().rsplit(")", 1)[1].split()
+            threads.append(((int(f[11]) + int(f[12])) / tick, comm, tid))
+        except OSError:
+            pass
+    print("threads by CPU seconds:", ", ".join(f"{c} {t:.2f}s" for t, c, _ in sorted(threads, reverse=True)[:10]), f"({len(threads)} threads)")
     for k, (c, t) in sorted(ACC.items(), key=lambda kv: -kv[1][1]):
         print(f"   {k:58s} {c / n:6.1f} calls  {t / n * 1e3:8.3f} ms/step")
 

@@ -36,6 +36,10 @@ def main():
     opt = build_optimizer(model, cfg.OPTIMIZATION)
     sched, _ = build_scheduler(opt, 100, 1, -1, cfg.OPTIMIZATION)
     fn = model_fn_decorator()
+    if os.environ.get("RD_DP_REHEARSE") == "1":          # the data-parallel path in a world of one rank (dist.rehearsal)
+        from radardistill_amd import dist as D
+        D.init_distributed(backend="nccl", device=device)
+        model = D.data_parallel(model, opt, 0)
     batches = [B.device_batch(make_batch(batch_size=args.batch, n_lidar=35000, n_radar=2000, n_boxes=30, grid=args.grid, seed=i), device)
                for i in range(2)]
 
