@@ -104,6 +104,7 @@ class FusedAdamOneCycle:
         self.present = None            # data parallelism: per-parameter "some rank has a gradient" mask, all-reduced every step
         self._static_cols = None
         self._param_ptrs = None
+        self._grad_col = None
         self.flat_grad = None          # data parallelism: see enable_flat_allreduce()
         self.process_group = None
 
@@ -233,8 +234,7 @@ class FusedAdamOneCycle:
             self._work_of[b] = w
 
     def zero_grad(self):
-        for p in self.params:
-            p.grad = None
+        native.lib().clear_grads(self.params)          # p.grad = None for every parameter (one loop in C)
         if getattr(self, 'buckets', None) is not None and (self._works or any(self.buckets.seen)):
             # a backward pass that was not followed by step() (it raised, or its step was abandoned): collectives in flight are
             # drained and the bucket bookkeeping starts clean, instead of carrying half-counted buckets into the next pass
@@ -246,22 +246,25 @@ class FusedAdamOneCycle:
     def _fill_table(self):
         # gradient tensors are new objects every step but, in steady state, the allocator hands back the same addresses: when a
         # ring slot was filled from exactly these pointers its device copy is still valid -- no refill, no host->device copy
-        grads = []
-        for i, p in enumerate(self.params):
-            g = p.grad
-            if g is None:                      # parameter unused this step: NULL = only the decoupled decay touches it (Adam skips it)
-                grads.append(0)
-                continue
-            if not g.is_contiguous() or g.dtype != torch.float32:
-                g = p.grad = g.float().contiguous()
-            grads.append(g.data_ptr())
+        # (the loop over the ~480 parameters -- p.grad, contiguity, dtype, data_ptr -- runs in the C helper native.lib().grad_ptrs)
+        cur = self._grad_col
+        if cur is None or cur.shape[0] != len(self.params):
+            cur = self._grad_col = np.zeros(len(self.params), dtype=np.int64)
+        L = native.lib()
+        while True:
+            r = L.grad_ptrs(self.params, torch.float32, cur)          # 0 for a parameter unused this step (Adam skips it: decay only)
+            if r > -2:
+                break
+            bad = self.params[-2 - r]
+            bad.grad = bad.grad.float().contiguous()
         pp = self._param_ptrs          # parameters keep their storage (optimizers update in place): revalidated by the two ends
         if pp is None or pp[0] != self.params[0].data_ptr() or pp[-1] != self.params[-1].data_ptr():
             pp = self._param_ptrs = tuple(p.data_ptr() for p in self.params)
-        sig = (tuple(grads), pp)
         for slot in range(self._ring):
-            if self._slot_sig[slot] == sig:
+            sg = self._slot_sig[slot]
+            if sg is not None and sg[1] is pp and np.array_equal(sg[0], cur):
                 return self.table_dev[slot]
+        grads = cur
         self._slot = (self._slot + 1) % self._ring
         ev = self._copied[self._slot]
         if ev is not None:
@@ -281,7 +284,7 @@ class FusedAdamOneCycle:
             static = self._static_cols = (tuple(int(v) for v in cols[:, 0]), cols)
         tab[:] = static[1]
         tab[:, 1] = grads
-        self._slot_sig[self._slot] = sig
+        self._slot_sig[self._slot] = (cur.copy(), pp)
         dev_t.copy_(host, non_blocking=True)
         if dev_t.is_cuda:
             ev = torch.cuda.Event()
