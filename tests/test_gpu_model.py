@@ -584,8 +584,10 @@ def test_bf16x3_conv_math_parity(golden_dir):
         # losses / tb entries keep the 1e-3..2e-3 bounds; the whole-network gradient comparison sees more ReLU sign flips at 4e-6
         # forward noise than at 4e-7, hence the wider multiples of the fp32 oracle's own distance from the fp64 gradient
         # (bf16x3 products carry 4e-6 instead of 4e-7: ~10x the pre-activations change sign, also in tensors where the fp32 oracle
-        # happens to have no flip at all, hence a per-tensor floor of 5e-2; the whole gradient stays within 6x the fp32 oracle's distance: measured 2.8x - 4.8x)
-        test_full_distillation_step_vs_oracle(noise_factor=8.0, whole_factor=6.0, tensor_tol=5e-2)
+        # happens to have no flip at all, hence a per-tensor floor of 4e-2.  Round 3: against the LARGEST of the three fp32-oracle draws
+        # the whole bf16x3 gradient sits at 3.1x (5.8e-2 vs 1.84e-2) and the worst tensor at 0.45 of the former (8x, 5e-2) bound, so the
+        # bounds came down from 8x / 6x / 5e-2 to 6x / 4.5x / 4e-2)
+        test_full_distillation_step_vs_oracle(noise_factor=6.0, whole_factor=4.5, tensor_tol=4e-2)
     finally:
         K.set_conv_math("f32")
 
