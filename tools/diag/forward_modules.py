@@ -2,6 +2,8 @@
 device sync inside the step, host-bound batch by default.  Says where the ~5 ms of forward host time outside the autograd Functions go.
 
     python tools/diag/forward_modules.py [batch=1] [steps=40]
+        RD_DP_REHEARSE=1            the data-parallel path in a world of one rank (hooks, bucket launches, RCCL calls), optimizer methods timed
+        RD_DIAG_TRAINING_STREAM=1   the loop on a high-priority stream, as bench.py runs it
 """
 import collections
 import os
@@ -54,13 +56,6 @@ def main():
         A._flush_deferred_layouts = timed("_flush_deferred_layouts", A._flush_deferred_layouts)
         A.deliver_grads = timed("deliver_grads", A.deliver_grads)
     batches = [B.device_batch(make_batch(batch_size=batch, n_lidar=35000, n_radar=2000, n_boxes=30, grid=512, seed=i), device) for i in range(2)]
-
-    def step(it):
-        sched.step(it)
-        opt.zero_grad()
-        loss, tb, _ = fn(model, dict(batches[it % 2]))
-        loss.backward()
-        opt.step()
 
     if os.environ.get("RD_DIAG_TRAINING_STREAM") == "1":          # as bench.py: the loop on a high-priority stream
         from radardistill_amd.train import use_training_stream
