@@ -832,10 +832,11 @@ def bn_act_train_tensors(x, gamma, beta, running_mean, running_var, eps, momentu
     return _BNActFn.apply(x, gamma, beta, None, running_mean, running_var, eps, momentum, act, stats, group)
 
 
-# One library call per layer and direction (composite.hip).  OFF by default: measured neutral to slightly negative (round 3, host-bound
-# B = 2 step 15.6 ms per-launch vs 15.9 ms composite; B = 8 18.5 vs 18.6) -- the four C calls it merges cost ~4 us each, while the
-# host time of a layer is torch's own: tensor allocations, Function.apply, saved tensors, the engine's node bookkeeping.
-COMPOSITE = [os.environ.get("RD_COMPOSITE", "0") == "1"]
+# One library call per layer and direction (composite.hip).  ON by default (RD_COMPOSITE=0 disables).  Run against run it looked
+# neutral (a box's host loop drifts between 13 and 19 ms per step within a minute); alternating the switch step by step inside ONE
+# process (tools/diag/toggle_ab.py, 150 + 100 steps per arm, device idle at every step start) it saves 0.36-0.48 ms of host time per
+# step: median 18.71 -> 18.35 ms at B = 1, 13.58 -> 13.10 ms at B = 8 (minima 17.63 -> 17.24, 12.52 -> 12.09).
+COMPOSITE = [os.environ.get("RD_COMPOSITE", "1") != "0"]
 
 
 def _side_handles(dev, param):
