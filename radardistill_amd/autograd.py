@@ -1028,9 +1028,20 @@ def rows_to_dense(feats, coords, batch, H, W):
 
 
 # ------------------------------------------------------------------------------------------ dense map helpers
+# A map produced by rows_to_nchw remembers the rows tensor it is a view of, and nchw_to_rows hands that tensor back: consecutive layers
+# then pass the SAME (rows) tensor along -- no permute / reshape in the forward, and above all no View / Permute backward nodes
+# between two layers' backward functions (module boundaries keep their logical NCHW tensors; the map and its rows share memory and
+# version counter, so an in-place change of one is seen by the other).  RD_ROWS_SHORTCUT=0 disables.
+ROWS_SHORTCUT = [os.environ.get("RD_ROWS_SHORTCUT", "1") != "0"]
+
+
 def nchw_to_rows(x):
     """(B,C,H,W) tensor -> (rows (B*H*W, C) view/copy, B, H, W).  Channels-last memory is a free view."""
     B, C, H, W = x.shape
+    if ROWS_SHORTCUT[0] and not CAPTURING[0]:          # (a capture works on static tensors that outlive the step)
+        r = getattr(x, "_rd_rows", None)
+        if r is not None and r.shape[0] == B * H * W and r.shape[1] == C:
+            return r, B, H, W
     xr = x.permute(0, 2, 3, 1)
     if not xr.is_contiguous():
         xr = xr.contiguous()
@@ -1039,7 +1050,9 @@ def nchw_to_rows(x):
 
 def rows_to_nchw(rows, B, H, W):
     """(B*H*W, C) rows -> logical (B,C,H,W) tensor in channels-last memory (no copy)."""
-    return rows.view(B, H, W, rows.shape[1]).permute(0, 3, 1, 2)
+    out = rows.view(B, H, W, rows.shape[1]).permute(0, 3, 1, 2)
+    out._rd_rows = rows
+    return out
 
 
 class _Cat2Fn(torch.autograd.Function):

@@ -3,6 +3,7 @@ build's host loop was seen between 13.2 and 19.3 ms per step on one box within a
 and the minimum host time of a step per arm.
 
     python tools/diag/toggle_ab.py composite [batch=1] [steps=200]          (autograd.COMPOSITE: one library call per layer and direction)
+    python tools/diag/toggle_ab.py nochk                                     (kernels._chk replaced by a no-op: what argument validation costs)
 """
 import os
 import statistics
@@ -33,9 +34,18 @@ def main():
     fn = model_fn_decorator()
     batches = [B.device_batch(make_batch(batch_size=batch, n_lidar=35000, n_radar=2000, n_boxes=30, grid=512, seed=i), device) for i in range(2)]
 
+    _chk0 = K._chk
+
+    def _nochk(t, *a, **k):
+        return t
+
     def set_arm(arm):
         if what == "composite":
             A.COMPOSITE[0] = bool(arm)
+        elif what == "rows":          # autograd.ROWS_SHORTCUT: consecutive layers pass the rows tensor along
+            A.ROWS_SHORTCUT[0] = bool(arm)
+        elif what == "nochk":          # how much the wrappers' argument validation costs (kernels._chk): an upper bound for caching it
+            K._chk = _nochk if arm else _chk0
         else:
             raise SystemExit(f"unknown switch {what}")
 
