@@ -574,7 +574,26 @@ class ConvSpec:
         self.fwd_nbr, self.bwd_nbr = fwd_nbr, bwd_nbr
 
 
+# Small per-layer host costs (round 3, measured together by step-by-step alternation, tools/diag/toggle_ab.py): the geometry spec of a
+# dense layer and of a linear layer is built once per shape instead of once per call (49 + 21 calls per step), and a BatchNorm module's
+# four tensors are looked up in its own dictionaries instead of through nn.Module.__getattr__ (4 slow attribute reads per layer).
+HOT_CACHES = [os.environ.get("RD_HOT_CACHES", "1") != "0"]
+_DENSE_SPECS, _LINEAR_SPECS = {}, {}
+
+
 def dense_conv_spec(B, Hin, Win, KH, KW, stride, pad, transposed=False):
+    if HOT_CACHES[0]:
+        key = (B, Hin, Win, KH, KW, stride, pad, transposed)
+        spec = _DENSE_SPECS.get(key)
+        if spec is None:
+            if len(_DENSE_SPECS) > 512:
+                _DENSE_SPECS.clear()
+            spec = _DENSE_SPECS[key] = _dense_conv_spec(B, Hin, Win, KH, KW, stride, pad, transposed)
+        return spec
+    return _dense_conv_spec(B, Hin, Win, KH, KW, stride, pad, transposed)
+
+
+def _dense_conv_spec(B, Hin, Win, KH, KW, stride, pad, transposed=False):
     if not transposed:
         Hout = (Hin + 2 * pad - KH) // stride + 1
         Wout = (Win + 2 * pad - KW) // stride + 1
@@ -593,6 +612,17 @@ def dense_conv_spec(B, Hin, Win, KH, KW, stride, pad, transposed=False):
 
 
 def linear_spec(rows):
+    if HOT_CACHES[0]:
+        spec = _LINEAR_SPECS.get(rows)
+        if spec is None:
+            if len(_LINEAR_SPECS) > 512:
+                _LINEAR_SPECS.clear()
+            spec = _LINEAR_SPECS[rows] = _linear_spec(rows)
+        return spec
+    return _linear_spec(rows)
+
+
+def _linear_spec(rows):
     fwd = K.conv_index_dense(1, rows, 1, rows, 1, 1, 1, 1, 0)
     bwd = K.conv_index_dense(1, rows, 1, rows, 1, 1, 1, 1, 0)
     return ConvSpec(1, rows, rows, fwd, bwd, 0)
@@ -959,8 +989,24 @@ def conv_bn_act_train(x, weight, bias, spec, Cout, bn, residual=None, act=1):
     if spec.out_rows <= 1 and group is None:
         raise ValueError("Expected more than 1 value per channel when training")     # torch's own train-mode BN error
     _BN_TOUCHED.append(bn)
+    if HOT_CACHES[0]:
+        gamma, beta, rm, rv, eps, mom = bn_tensors(bn)
+        return _ConvBNActFn.apply(x, weight, bias, spec, Cout, gamma, beta, residual, rm, rv, eps, mom, act, group)
     return _ConvBNActFn.apply(x, weight, bias, spec, Cout, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, float(bn.eps),
                               float(bn.momentum), act, group)
+
+
+def bn_tensors(bn):
+    """(weight, bias, running_mean, running_var, eps, momentum) of a BatchNorm module, read from the module's own dictionaries:
+    `bn.weight` goes through nn.Module.__getattr__ (a Python function that searches three dictionaries), `bn._parameters["weight"]` does not."""
+    p, b = bn._parameters, bn._buffers
+    return p["weight"], p["bias"], b["running_mean"], b["running_var"], float(bn.eps), float(bn.momentum)
+
+
+def conv_params(conv):
+    """(weight, bias) of a convolution / linear container, without nn.Module.__getattr__ (see bn_tensors)."""
+    p = conv._parameters
+    return p["weight"], p.get("bias")
 
 
 _BN_FOLD_CACHE = {}

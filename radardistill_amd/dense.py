@@ -42,7 +42,8 @@ def conv_bn_act(x, conv, bn=None, residual_rows=None, act=1, return_rows=False, 
         scale, shift = A.bn_eval_scale_shift(bn)
         out = A.conv_inference(rows, conv.weight, conv.bias, spec, Cout, scale, shift, residual_rows, act == 1)
     elif bn.training:
-        out = A.conv_bn_act_train(rows, conv.weight, conv.bias, spec, Cout, bn, residual_rows, act)
+        w, b = A.conv_params(conv)
+        out = A.conv_bn_act_train(rows, w, b, spec, Cout, bn, residual_rows, act)
     else:
         raw = A.conv(rows, conv.weight, conv.bias, spec, Cout, None)
         out = A.bn_act_eval(raw, bn, residual_rows, act=act)

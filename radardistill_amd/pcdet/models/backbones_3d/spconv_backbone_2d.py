@@ -97,8 +97,11 @@ class SparseBasicBlock(spconv.SparseModule):
             y = A.conv_inference(f, self.conv1.weight, self.conv1.bias, spec, C, s1, h1, None, True)
             y = A.conv_inference(y, self.conv2.weight, self.conv2.bias, spec, C, s2, h2, f, True)
         elif self.bn1.training:
-            y = A.conv_bn_act_train(f, self.conv1.weight, self.conv1.bias, spec, C, self.bn1, None, 1)
-            y = A.conv_bn_act_train(y, self.conv2.weight, self.conv2.bias, spec, C, self.bn2, f, 1)
+            m = self._modules          # (plain dictionary reads instead of nn.Module.__getattr__: autograd.bn_tensors)
+            w1, b1 = A.conv_params(m['conv1'])
+            w2, b2 = A.conv_params(m['conv2'])
+            y = A.conv_bn_act_train(f, w1, b1, spec, C, m['bn1'], None, 1)
+            y = A.conv_bn_act_train(y, w2, b2, spec, C, m['bn2'], f, 1)
         else:
             y = A.conv(f, self.conv1.weight, self.conv1.bias, spec, C, None)
             y = A.bn_act_eval(y, self.bn1, None, act=1)

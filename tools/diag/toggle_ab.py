@@ -44,6 +44,8 @@ def main():
             A.COMPOSITE[0] = bool(arm)
         elif what == "rows":          # autograd.ROWS_SHORTCUT: consecutive layers pass the rows tensor along
             A.ROWS_SHORTCUT[0] = bool(arm)
+        elif what == "hot":          # autograd.HOT_CACHES: cached geometry specs and BatchNorm tensor lookups
+            A.HOT_CACHES[0] = bool(arm)
         elif what == "nochk":          # how much the wrappers' argument validation costs (kernels._chk): an upper bound for caching it
             K._chk = _nochk if arm else _chk0
         else:
