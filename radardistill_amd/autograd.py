@@ -996,6 +996,27 @@ def conv_bn_act_train(x, weight, bias, spec, Cout, bn, residual=None, act=1):
                               float(bn.momentum), act, group)
 
 
+def fast_module_attrs(model, on=True):
+    """Mirror every submodule and parameter of `model` into its owner's instance dictionary, so that `self.conv1` / `conv.weight` are
+    plain attribute reads instead of calls of nn.Module.__getattr__ (a Python function searching three dictionaries; ~1200 such
+    reads per training step).  nn.Module.__setattr__ removes the mirror entry of a name it re-assigns, Module.to() and
+    load_state_dict() keep parameter objects, buffers are NOT mirrored (Module.to() replaces them); register_parameter /
+    register_module on an existing name after this call would leave a stale mirror -- call again then.  on=False removes the mirrors."""
+    for m in model.modules():
+        d = m.__dict__
+        for name, child in m._modules.items():
+            if on and child is not None:
+                d[name] = child
+            else:
+                d.pop(name, None)
+        for name, p in m._parameters.items():
+            if on and p is not None:
+                d[name] = p
+            else:
+                d.pop(name, None)
+    return model
+
+
 def bn_tensors(bn):
     """(weight, bias, running_mean, running_var, eps, momentum) of a BatchNorm module, read from the module's own dictionaries:
     `bn.weight` goes through nn.Module.__getattr__ (a Python function that searches three dictionaries), `bn._parameters["weight"]` does not."""

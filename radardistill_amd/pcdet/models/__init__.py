@@ -1,5 +1,6 @@
 """build_network / load_data_to_gpu / model_fn_decorator: the reference's training entry points
 (pcdet/models/__init__.py:16-54)."""
+import os
 from collections import namedtuple
 
 import numpy as np
@@ -9,7 +10,13 @@ from .detectors import build_detector
 
 
 def build_network(model_cfg, num_class, dataset):
-    return build_detector(model_cfg=model_cfg, num_class=num_class, dataset=dataset)
+    model = build_detector(model_cfg=model_cfg, num_class=num_class, dataset=dataset)
+    if os.environ.get("RD_FAST_ATTRS", "1") != "0":
+        # submodules and parameters mirrored into the instance dictionaries: `self.conv1` / `conv.weight` become plain attribute reads
+        # instead of nn.Module.__getattr__ calls (~1200 per training step, -0.2 ms; autograd.fast_module_attrs says when it is safe)
+        from radardistill_amd import autograd as A
+        A.fast_module_attrs(model)
+    return model
 
 
 _COPY_STREAM = {}

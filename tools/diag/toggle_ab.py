@@ -46,6 +46,8 @@ def main():
             A.ROWS_SHORTCUT[0] = bool(arm)
         elif what == "hot":          # autograd.HOT_CACHES: cached geometry specs and BatchNorm tensor lookups
             A.HOT_CACHES[0] = bool(arm)
+        elif what == "attrs":          # autograd.fast_module_attrs: submodules / parameters mirrored into the instance dictionaries
+            A.fast_module_attrs(model, on=bool(arm))
         elif what == "nochk":          # how much the wrappers' argument validation costs (kernels._chk): an upper bound for caching it
             K._chk = _nochk if arm else _chk0
         else:
