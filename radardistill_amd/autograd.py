@@ -633,15 +633,16 @@ class _ConvFn(torch.autograd.Function):
     or fused BatchNorm statistics (stats) in training."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, spec, Cout, stats, bias_feeds_bn=False):
-        out = _ConvFn.forward_impl(ctx, x, weight, bias, spec, Cout, stats)
+    def forward(ctx, x, weight, bias, spec, Cout, stats, bias_feeds_bn=False, residual=None):
+        out = _ConvFn.forward_impl(ctx, x, weight, bias, spec, Cout, stats, residual)
         ctx.bias_feeds_bn = bool(bias_feeds_bn)
         ctx.save_for_backward(x, weight)
         return out
 
     @staticmethod
-    def forward_impl(ctx, x, weight, bias, spec, Cout, stats):
-        """The convolution launch + what its backward needs on `ctx` (shared with _ConvBNActFn); the caller saves x and weight."""
+    def forward_impl(ctx, x, weight, bias, spec, Cout, stats, residual=None):
+        """The convolution launch + what its backward needs on `ctx` (shared with _ConvBNActFn); the caller saves x and weight.
+        residual (rows x Cout): added in the kernel's epilogue (out = conv + bias + residual; its gradient is grad_out itself)."""
         Cin = x.shape[1]
         note_param_use(weight, bias)
         ctx.xs = None
@@ -649,7 +650,7 @@ class _ConvFn(torch.autograd.Function):
             wk = None
             frag = K.wants_frag_weights(spec.fwd_ix, spec.in_rows, spec.out_rows, Cin, Cout, spec.taps)
             out = K.conv_fwd(x, operand_weight_split(weight, Cout, Cin, spec.taps, spec.param_kind, frag=frag), spec.taps, bias, spec.out_rows, Cout,
-                             spec.fwd_ix, stats=stats, nbr_keepalive=spec.fwd_nbr, w_split=2 if frag else True)
+                             spec.fwd_ix, stats=stats, nbr_keepalive=spec.fwd_nbr, w_split=2 if frag else True, residual=residual)
             ctx.spec, ctx.Cout, ctx.Cin = spec, Cout, Cin
             ctx.has_bias = bias is not None
             ctx.bias_ref = bias
@@ -659,9 +660,9 @@ class _ConvFn(torch.autograd.Function):
         if _b3_presplit(Cin, Cout, spec.fwd_ix.mode):
             ctx.xs = split_activation(x)              # reused by the weight gradient
             out = K.conv_fwd(ctx.xs, kernel_weight_split(weight, wk, Cout, Cin, spec.taps), spec.taps, bias, spec.out_rows, Cout, spec.fwd_ix,
-                             stats=stats, nbr_keepalive=spec.fwd_nbr, in_split=True, w_split=True)
+                             stats=stats, nbr_keepalive=spec.fwd_nbr, in_split=True, w_split=True, residual=residual)
         else:
-            out = K.conv_fwd(x, wk, spec.taps, bias, spec.out_rows, Cout, spec.fwd_ix, stats=stats, nbr_keepalive=spec.fwd_nbr)
+            out = K.conv_fwd(x, wk, spec.taps, bias, spec.out_rows, Cout, spec.fwd_ix, stats=stats, nbr_keepalive=spec.fwd_nbr, residual=residual)
         ctx.spec, ctx.Cout, ctx.Cin = spec, Cout, Cin
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias
@@ -671,9 +672,12 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         x, weight = ctx.saved_tensors
-        gx, gw, gb = _ConvFn.backward_impl(ctx, x, weight, grad_out.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                           ctx.needs_input_grad[2])
-        return gx, gw, gb, None, None, None, None
+        go = grad_out.contiguous()
+        gx, gw, gb = _ConvFn.backward_impl(ctx, x, weight, go, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        n = ctx.needs_input_grad
+        if len(n) == 7:          # called without a residual
+            return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, (go if n[7] else None)
 
     @staticmethod
     def backward_impl(ctx, x, weight, grad_out, need_x, need_w, need_b):
@@ -750,10 +754,13 @@ class _ConvFn(torch.autograd.Function):
             return gw
 
 
-def conv(x, weight, bias, spec, Cout, stats=None, bias_feeds_bn=False):
+def conv(x, weight, bias, spec, Cout, stats=None, bias_feeds_bn=False, residual=None):
     """bias_feeds_bn: the output is consumed only by a train-mode BatchNorm (whose statistics `stats` collects): the bias gradient is
-    then identically zero and no column sum is launched for it."""
-    return _ConvFn.apply(x, weight, bias, spec, Cout, stats, bias_feeds_bn)
+    then identically zero and no column sum is launched for it.  residual: added in the epilogue (one launch and one autograd node
+    less than `conv(...) + residual`)."""
+    if residual is None:
+        return _ConvFn.apply(x, weight, bias, spec, Cout, stats, bias_feeds_bn)
+    return _ConvFn.apply(x, weight, bias, spec, Cout, stats, bias_feeds_bn, residual)
 
 
 def conv_inference(x, weight, bias, spec, Cout, scale=None, shift=None, residual=None, relu=False):

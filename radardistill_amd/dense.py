@@ -50,6 +50,7 @@ def conv_bn_act(x, conv, bn=None, residual_rows=None, act=1, return_rows=False, 
     return (out, B, Ho, Wo) if return_rows else A.rows_to_nchw(out, B, Ho, Wo)
 
 
-def linear_rows(rows, lin):
-    """nn.Linear container on (rows, Cin) -> (rows, Cout) through the 1-tap implicit GEMM."""
-    return A.conv(rows, lin.weight, lin.bias, A.linear_spec(rows.shape[0]), lin.out_features, None)
+def linear_rows(rows, lin, residual=None):
+    """nn.Linear container on (rows, Cin) -> (rows, Cout) through the 1-tap implicit GEMM (+ residual rows in the epilogue)."""
+    w, b = A.conv_params(lin)
+    return A.conv(rows, w, b, A.linear_spec(rows.shape[0]), lin.out_features, None, residual=residual)

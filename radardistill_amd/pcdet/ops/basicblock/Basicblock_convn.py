@@ -76,11 +76,16 @@ class ConvNeXtBlock(nn.Module):
         C = rows.shape[1]
         identity = rows
         y = A.dwconv(rows, self.dwconv, B, H, W)                                             # depthwise 7x7 (dwconv.hip)
-        y = self.norm(y.view(B, H, W, C))
-        y = D.linear_rows(y.reshape(-1, C), self.pwconv1)
+        norm = self.norm
+        if y.is_cuda and y.dtype == torch.float32 and norm.data_format == "channels_last" and C % 4 == 0 and C <= 1024 and y.is_contiguous():
+            y = A.layer_norm_rows(y, norm.weight, norm.bias, norm.eps)                       # layernorm.hip, rows in, rows out (no views)
+        else:
+            y = norm(y.view(B, H, W, C)).reshape(-1, C)
+        y = D.linear_rows(y, self.pwconv1)
         if y.is_cuda and isinstance(self.act, nn.GELU) and getattr(self.act, 'approximate', 'none') == 'none':
             y = A.gelu_grn(y, self.grn, B)                                                   # GELU + GRN fused (convnext.hip)
         else:
             y = self.grn(self.act(y).view(B, H, W, 4 * C)).reshape(-1, 4 * C)
-        y = D.linear_rows(y.reshape(-1, 4 * C), self.pwconv2)
-        return A.rows_to_nchw(y + identity, B, H, W)
+        if y.is_cuda:
+            return A.rows_to_nchw(D.linear_rows(y, self.pwconv2, residual=identity), B, H, W)          # + identity in the GEMM's epilogue
+        return A.rows_to_nchw(D.linear_rows(y.reshape(-1, 4 * C), self.pwconv2) + identity, B, H, W)
