@@ -40,3 +40,29 @@ def test_sync_batchnorm_two_ranks_equal_one_process_on_all_rows():
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_syncbn_check.py")]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DIST_SYNCBN_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_rccl_one_rank_rehearsal_of_the_data_parallel_step(overlap):
+    """RD_DP_REHEARSE=1 (dist.rehearsal): the bench's training loop with the complete data-parallel path -- RCCL process group, parameter
+    broadcast, flat-buffer exchange (unbucketed by default, bucketed + overlapped with RD_DDP_OVERLAP=1), presence mask, clip + Adam from
+    the flat buffer -- in a world of ONE rank on this GPU (two RCCL ranks cannot share a device).  In a world of one the exchange is
+    the identity, so the loss after three optimizer steps must equal the plain loop's on the same batches; what the test is for is
+    that every RCCL call, stream hand-over and work handle of the N > 1 path has executed on the hardware."""
+    import json
+    losses = {}
+    for rehearse in ("0", "1"):
+        env = dict(os.environ, RD_DP_REHEARSE=rehearse, RD_DDP_OVERLAP=overlap, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(_free_port()), RD_BENCH_NO_HOOKS="1")
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+            env.pop(k, None)
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "2", "--steps", "3", "--warmup", "0", "--no-cpu-baseline",
+               "--other-math-steps", "0", "--amp-steps", "0"]
+        r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert r.returncode == 0 and lines, (r.stdout[-1500:], r.stderr[-3000:])
+        out = json.loads(lines[-1])
+        assert out["n_gpus"] == 1 and out["steps"] == 3
+        losses[rehearse] = out["config"]["final_loss"]
+    import math
+    assert math.isfinite(losses["1"]) and abs(losses["1"] - losses["0"]) <= 2e-3 * abs(losses["0"]), losses
